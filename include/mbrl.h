@@ -1,0 +1,88 @@
+/*
+ * mbrl.h -- C ABI of the MI355X-native FD-linearisation path (libmbrl_hip.so).
+ *
+ * The reference (MahanFathi/Model-Based-RL) has no FFI of its own: its hot path is the
+ * Python protocol  MjBlock.forward/backward  (model/blocks/mujoco.py:12-104) over
+ * mj_forward / calculate_gradients (mujoco/utils/forward.py:13-38,
+ * mujoco/utils/backward.py:343-480), which reach MuJoCo through mujoco-py.  These entry
+ * points are what a binding for that path would bind; each cites what it replaces.
+ *
+ * Conventions: plain C, no C++/torch types.  Every pointer named q*, ctrl, ds*, dr*,
+ * s_next, reward, status is DEVICE memory (HBM) owned by the caller, row-major,
+ * fp64 (status: uint32).  Calls are asynchronous on `hip_stream` (a hipStream_t, may be
+ * NULL for the default stream).  The library allocates nothing per call and keeps no
+ * mutable global state: a model handle is immutable after creation, so calls are
+ * re-entrant.  Return value 0 = ok, negative = error (text via mbrl_last_error()).
+ */
+#ifndef MBRL_H
+#define MBRL_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MBRL_ABI_VERSION 1
+
+/* per-unit status bits (replace mujoco-py's MujocoException / the reference's asserts,
+ * backward.py:371,374) */
+#define MBRL_ST_NONFINITE  1u  /* NaN/Inf state or non-positive pivot */
+#define MBRL_ST_NOCONVERGE 2u  /* constraint solver hit its iteration cap */
+#define MBRL_ST_OVERFLOW   4u  /* reserved (contact capacity) */
+
+#define MBRL_FD_FORWARD 0      /* reference parity: one-sided, (f(x+eps)-f(x))/eps, backward.py:402-406 */
+#define MBRL_FD_CENTRAL 1      /* (f(x+eps)-f(x-eps))/(2 eps) */
+
+typedef struct mbrl_model mbrl_model;
+
+int mbrl_abi_version(void);
+
+/* Replaces build_agent(cfg) -> env ctor (mujoco/build.py:6-37, e.g.
+ * mujoco/envs/half_cheetah.py:15-22): env_name is cfg.MUJOCO.ENV ("HalfCheetahEnv",
+ * "HopperEnv", "Walker2dEnv", "SwimmerEnv", "InvertedPendulumEnv",
+ * "InvertedDoublePendulumEnv"), frame_skip is cfg.MODEL.FRAME_SKIP (<=0: the yaml's
+ * value for that env), device is the HIP device ordinal the handle launches on. */
+int mbrl_model_create(const char *env_name, int frame_skip, int device, mbrl_model **out);
+void mbrl_model_destroy(mbrl_model *m);
+
+/* agent.model.nq / nv / nu and env.dt (= timestep * frame_skip). */
+int mbrl_model_dims(const mbrl_model *m, int *nq, int *nv, int *nu, double *dt);
+
+/* Replaces mj_forward() -> agent.step(action) (mujoco/utils/forward.py:13-38; env.step
+ * e.g. mujoco/envs/half_cheetah.py:24-33): N independent units, one env step each.
+ * qpos [N,nq], qvel [N,nv], ctrl [N,nu] -> qpos_next, qvel_next, reward [N], status [N]. */
+int mbrl_step(const mbrl_model *m, int64_t N, const double *qpos, const double *qvel, const double *ctrl,
+              double *qpos_next, double *qvel_next, double *reward, uint32_t *status, void *hip_stream);
+
+/* Replaces calculate_gradients(agent, snapshot, next_state, reward, test=True)
+ * (mujoco/utils/backward.py:343-480) for N snapshots in ONE launch.  eps is
+ * backward.py:13 (1e-6), nsteps is cfg.MODEL.NSTEPS_FOR_BACKWARD (backward.py:359).
+ * With n = nq+nv:
+ *   dsds [N,n,n]   rows = outputs (qpos',qvel'), cols = inputs (qpos,qvel)   (backward.py:475 "state")
+ *   dsda [N,n,nu]                                                            (backward.py:475 "action")
+ *   drds [N,n], drda [N,nu]                                                  (backward.py:478)
+ *   s_next [N,n], reward [N]: the nominal rollout (the `test=True` re-step, backward.py:362-374)
+ * Any output pointer may be NULL. */
+int mbrl_fd_jacobians(const mbrl_model *m, int64_t N, const double *qpos, const double *qvel,
+                      const double *ctrl, double eps, int fd_mode, int nsteps, double *dsds, double *dsda,
+                      double *drds, double *drda, double *s_next, double *reward, uint32_t *status,
+                      void *hip_stream);
+
+/* Replaces the chain of MjBlock.backward calls that autograd issues for one epoch
+ * (model/blocks/mujoco.py:43-104; recurrence in SURVEY.md App. C): for each of B
+ * episodes, t = H-1..0:
+ *     da[b,t] = w_t * ( c[b,t]*drda[b,t] + g * dsda[b,t] ),  g <- c[b,t]*drds[b,t] + g * dsds[b,t]
+ * Jacobians are indexed [b*H + t].  grad_weights: 0 = none, 1 = 'average' (w_t = 1/(H-t)),
+ * 2 = 'prioritise' (running-sum weights, mujoco.py:46-47,57-58,64-65,72-74; the running sum
+ * restarts at 0 for every call = trainer.py:76).  c [B,H] = dL/dreward; outputs da [B,H,nu]
+ * and ds0 [B,n] (gradient w.r.t. the initial state; may be NULL). */
+int mbrl_vjp_scan(const mbrl_model *m, int64_t B, int H, int grad_weights, const double *dsds,
+                  const double *dsda, const double *drds, const double *drda, const double *c, double *da,
+                  double *ds0, void *hip_stream);
+
+const char *mbrl_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,352 @@
+// mbrl_hip.hip -- HIP kernels (gfx950) + C ABI (include/mbrl.h) for the FD linearisation path.
+//
+// Work decomposition (MI355X, wave64):
+//   * one LANE per rollout (= one perturbed copy of one unit); a unit's 1+nu+nv+nq rollouts sit
+//     in consecutive lanes, so the lanes of a wave are perturbations of at most a few nominal
+//     states and follow the same contact / Newton control flow;
+//   * a 256-thread workgroup owns UPB = 256 / R whole units; rollout results meet in LDS and the
+//     workgroup writes that block of Jacobians with fully coalesced stores (the outputs of
+//     consecutive units are contiguous in every output array);
+//   * the path is fp64-VALU bound (~1 MFLOP per HalfCheetah unit vs 4 KB of HBM traffic), so the
+//     per-lane simulator (planar_sim.hpp) keeps its whole working set in registers.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/mbrl.h"
+#include "planar_sim.hpp"
+
+namespace mbrl {
+
+constexpr int kBlock = 256;
+
+template <class M, bool CENTRAL>
+struct FdShape {
+    static constexpr int NP = M::NU + 2 * M::NV;                 // perturbed inputs
+    static constexpr int R = CENTRAL ? 1 + 2 * NP : 1 + NP;     // rollouts per unit
+    static constexpr int UPB = kBlock / R;                      // units per workgroup
+    static constexpr int NS = 2 * M::NV;                        // state size n
+    static constexpr int ROW = NS + 1;                          // s' and reward
+};
+
+// column order of calculate_gradients: ctrl, then qvel, then qpos (backward.py:389,409,433)
+template <class M, bool CENTRAL>
+__global__ __launch_bounds__(kBlock) void fd_kernel(int64_t N, int frame_skip, int nsteps, double eps,
+                                                     const double *__restrict__ qpos,
+                                                     const double *__restrict__ qvel,
+                                                     const double *__restrict__ ctrl, double *__restrict__ dsds,
+                                                     double *__restrict__ dsda, double *__restrict__ drds,
+                                                     double *__restrict__ drda, double *__restrict__ s_next,
+                                                     double *__restrict__ reward, uint32_t *__restrict__ status) {
+    using Sh = FdShape<M, CENTRAL>;
+    constexpr int NV = M::NV, NU = M::NU, NS = Sh::NS, R = Sh::R, UPB = Sh::UPB, ROW = Sh::ROW;
+    __shared__ double res[UPB * R * ROW];
+    __shared__ unsigned stat[UPB];
+
+    const int t = threadIdx.x;
+    const int u = t / R, p = t - u * R;
+    const int64_t unit0 = int64_t(blockIdx.x) * UPB;
+    const int64_t unit = unit0 + u;
+    if (t < UPB) stat[t] = 0;
+    __syncthreads();
+
+    if (u < UPB && unit < N) {
+        Sim<M, double> S;
+        S.status = 0;
+        const double *qp = qpos + unit * NV, *vp = qvel + unit * NV, *cp = ctrl + unit * NU;
+#pragma unroll
+        for (int j = 0; j < NV; j++) { S.q[j] = qp[j]; S.v[j] = vp[j]; }
+#pragma unroll
+        for (int k = 0; k < NU; k++) S.ctrl[k] = cp[k];
+        if (p > 0) {
+            int idx = p - 1;
+            double d = eps;
+            if (CENTRAL) { d = (idx & 1) ? -eps : eps; idx >>= 1; }
+            // static indexing only: scan the inputs instead of indexing a register array
+#pragma unroll
+            for (int k = 0; k < NU; k++) if (idx == k) S.ctrl[k] += d;
+#pragma unroll
+            for (int j = 0; j < NV; j++) if (idx == NU + j) S.v[j] += d;
+#pragma unroll
+            for (int j = 0; j < NV; j++) if (idx == NU + NV + j) S.q[j] += d;
+        }
+        double r = 0.0;
+        for (int k = 0; k < nsteps; k++) r = S.env_step(frame_skip);
+        S.check_finite();
+        double *o = res + (u * R + p) * ROW;
+#pragma unroll
+        for (int j = 0; j < NV; j++) { o[j] = S.q[j]; o[NV + j] = S.v[j]; }
+        o[NS] = r;
+        if (S.status) atomicOr(&stat[u], S.status);
+    }
+    __syncthreads();
+
+    int64_t nun = N - unit0;
+    if (nun > UPB) nun = UPB;
+    const int nu_blk = int(nun);
+    const double den = CENTRAL ? 2.0 * eps : eps;
+    // perturbation slot of input column `in` (0..NU+2NV-1 in ctrl,qvel,qpos order)
+    auto plus = [](int in) { return CENTRAL ? 1 + 2 * in : 1 + in; };
+    auto minus = [](int in) { return CENTRAL ? 2 + 2 * in : 0; };
+
+    if (dsds) {  // [unit][o][col], col < NV: qpos input, else qvel input
+        double *base = dsds + unit0 * NS * NS;
+        for (int e = t; e < nu_blk * NS * NS; e += kBlock) {
+            const int uu = e / (NS * NS), rem = e - uu * NS * NS, o = rem / NS, col = rem - o * NS;
+            const int in = col < NV ? NU + NV + col : NU + (col - NV);
+            const double *ru = res + uu * R * ROW;
+            base[e] = (ru[plus(in) * ROW + o] - ru[minus(in) * ROW + o]) / den;
+        }
+    }
+    if (dsda) {
+        double *base = dsda + unit0 * NS * NU;
+        for (int e = t; e < nu_blk * NS * NU; e += kBlock) {
+            const int uu = e / (NS * NU), rem = e - uu * NS * NU, o = rem / NU, k = rem - o * NU;
+            const double *ru = res + uu * R * ROW;
+            base[e] = (ru[plus(k) * ROW + o] - ru[minus(k) * ROW + o]) / den;
+        }
+    }
+    if (drds) {
+        double *base = drds + unit0 * NS;
+        for (int e = t; e < nu_blk * NS; e += kBlock) {
+            const int uu = e / NS, col = e - uu * NS;
+            const int in = col < NV ? NU + NV + col : NU + (col - NV);
+            const double *ru = res + uu * R * ROW;
+            base[e] = (ru[plus(in) * ROW + NS] - ru[minus(in) * ROW + NS]) / den;
+        }
+    }
+    if (drda) {
+        double *base = drda + unit0 * NU;
+        for (int e = t; e < nu_blk * NU; e += kBlock) {
+            const int uu = e / NU, k = e - uu * NU;
+            const double *ru = res + uu * R * ROW;
+            base[e] = (ru[plus(k) * ROW + NS] - ru[minus(k) * ROW + NS]) / den;
+        }
+    }
+    if (s_next) {
+        double *base = s_next + unit0 * NS;
+        for (int e = t; e < nu_blk * NS; e += kBlock) {
+            const int uu = e / NS, o = e - uu * NS;
+            base[e] = res[uu * R * ROW + o];
+        }
+    }
+    if (t < nu_blk) {
+        if (reward) reward[unit0 + t] = res[t * R * ROW + NS];
+        if (status) status[unit0 + t] = stat[t];
+    }
+}
+
+template <class M>
+__global__ __launch_bounds__(kBlock) void step_kernel(int64_t N, int frame_skip, const double *__restrict__ qpos,
+                                                       const double *__restrict__ qvel,
+                                                       const double *__restrict__ ctrl,
+                                                       double *__restrict__ qpos_next,
+                                                       double *__restrict__ qvel_next, double *__restrict__ reward,
+                                                       uint32_t *__restrict__ status) {
+    constexpr int NV = M::NV, NU = M::NU;
+    const int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= N) return;
+    Sim<M, double> S;
+    S.status = 0;
+#pragma unroll
+    for (int j = 0; j < NV; j++) { S.q[j] = qpos[i * NV + j]; S.v[j] = qvel[i * NV + j]; }
+#pragma unroll
+    for (int k = 0; k < NU; k++) S.ctrl[k] = ctrl[i * NU + k];
+    const double r = S.env_step(frame_skip);
+    S.check_finite();
+#pragma unroll
+    for (int j = 0; j < NV; j++) { qpos_next[i * NV + j] = S.q[j]; qvel_next[i * NV + j] = S.v[j]; }
+    if (reward) reward[i] = r;
+    if (status) status[i] = S.status;
+}
+
+// Backward recurrence of the op chain (mujoco.py:43-104): one thread per (episode, output lane).
+// n <= 18, nu <= 6: each episode is walked by one 32-lane group; lane l owns g[l].
+__global__ __launch_bounds__(kBlock) void vjp_scan_kernel(int64_t B, int H, int n, int nu, int gw,
+                                                           const double *__restrict__ dsds,
+                                                           const double *__restrict__ dsda,
+                                                           const double *__restrict__ drds,
+                                                           const double *__restrict__ drda,
+                                                           const double *__restrict__ c, double *__restrict__ da,
+                                                           double *__restrict__ ds0) {
+    __shared__ double gs[kBlock / 32][32];
+    const int grp = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const int64_t b = int64_t(blockIdx.x) * (kBlock / 32) + grp;
+    const bool live = b < B;
+    double g = 0.0;  // g_{t+1}[l]
+    // 'prioritise': autograd runs episodes last-to-first, the running sum carries over (mujoco.py:65)
+    double S = live ? double(B - 1 - b) * (0.5 * double(H) * double(H + 1)) : 0.0;
+    for (int t = H - 1; t >= 0; t--) {
+        gs[grp][l] = g;
+        __syncthreads();
+        if (live) {
+            const int64_t k = b * H + t;
+            const double ct = c[k];
+            const double W = double(H - t);
+            double wa_r = 1.0, wa_d = 1.0, ws_r = 1.0;  // action weights (reward / dynamics op), state weight (reward op)
+            if (gw == 1) { wa_r = 1.0 / W; wa_d = 1.0 / W; }
+            else if (gw == 2) { S += W; ws_r = W - 1.0; wa_r = W / S; wa_d = 1.0 / S; }
+            if (l < nu) {
+                double acc = 0.0;
+                for (int o = 0; o < n; o++) acc += gs[grp][o] * (wa_d * dsda[(k * n + o) * nu + l]);
+                da[k * nu + l] = ct * (wa_r * drda[k * nu + l]) + acc;
+            }
+            if (l < n) {
+                double acc = 0.0;
+                for (int o = 0; o < n; o++) acc += gs[grp][o] * dsds[(k * n + o) * n + l];
+                g = ct * (ws_r * drds[k * n + l]) + acc;
+            }
+        }
+        __syncthreads();
+    }
+    if (live && ds0 && l < n) ds0[b * n + l] = g;
+}
+
+}  // namespace mbrl
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+using namespace mbrl;
+
+struct mbrl_model {
+    int env_id, frame_skip, device, nq, nv, nu;
+    double timestep;
+};
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, const char *a = "", long long b = 0) {
+    snprintf(g_err, sizeof g_err, fmt, a, b);
+    return code;
+}
+
+#define MBRL_DISPATCH(id, CALL)                                        \
+    switch (id) {                                                      \
+    case 0: { using M = MdlInvertedPendulum; CALL; } break;            \
+    case 1: { using M = MdlInvertedDoublePendulum; CALL; } break;      \
+    case 2: { using M = MdlSwimmer; CALL; } break;                     \
+    case 3: { using M = MdlHopper; CALL; } break;                      \
+    case 4: { using M = MdlWalker2d; CALL; } break;                    \
+    case 5: { using M = MdlHalfCheetah; CALL; } break;                 \
+    default: break;                                                    \
+    }
+
+static const char *kEnvNames[] = {"InvertedPendulumEnv", "InvertedDoublePendulumEnv", "SwimmerEnv",
+                                  "HopperEnv", "Walker2dEnv", "HalfCheetahEnv"};
+
+template <class M>
+static void fill_dims(mbrl_model *m) {
+    m->nq = M::NV; m->nv = M::NV; m->nu = M::NU; m->timestep = M::DT;
+    if (m->frame_skip <= 0) m->frame_skip = M::FRAME_SKIP;
+}
+
+static int check_launch(const mbrl_model *m, const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-10, "%s: launch failed (hip error %lld)", what, (long long)e);
+    (void)m;
+    return 0;
+}
+
+template <class M, bool CENTRAL>
+static void launch_fd(const mbrl_model *m, int64_t N, const double *qpos, const double *qvel, const double *ctrl,
+                      double eps, int nsteps, double *dsds, double *dsda, double *drds, double *drda,
+                      double *s_next, double *reward, uint32_t *status, hipStream_t st) {
+    using Sh = FdShape<M, CENTRAL>;
+    static_assert(Sh::UPB >= 1, "a unit's rollouts must fit one workgroup");
+    const int64_t blocks = (N + Sh::UPB - 1) / Sh::UPB;
+    hipLaunchKernelGGL((fd_kernel<M, CENTRAL>), dim3((unsigned)blocks), dim3(kBlock), 0, st, N, m->frame_skip, nsteps,
+                       eps, qpos, qvel, ctrl, dsds, dsda, drds, drda, s_next, reward, status);
+}
+
+extern "C" {
+
+int mbrl_abi_version(void) { return MBRL_ABI_VERSION; }
+
+const char *mbrl_last_error(void) { return g_err; }
+
+int mbrl_model_create(const char *env_name, int frame_skip, int device, mbrl_model **out) {
+    if (!env_name || !out) return fail(-1, "mbrl_model_create: null argument");
+    int id = -1;
+    for (int i = 0; i < 6; i++)
+        if (!strcmp(env_name, kEnvNames[i])) id = i;
+    if (id < 0) return fail(-2, "mbrl_model_create: unknown env '%s'", env_name);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(-3, "mbrl_model_create: no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(-4, "mbrl_model_create: bad device ordinal %s%lld", "", device);
+    mbrl_model *m = new (std::nothrow) mbrl_model();
+    if (!m) return fail(-5, "mbrl_model_create: out of host memory");
+    m->env_id = id; m->frame_skip = frame_skip; m->device = device;
+    MBRL_DISPATCH(id, fill_dims<M>(m));
+    *out = m;
+    return 0;
+}
+
+void mbrl_model_destroy(mbrl_model *m) { delete m; }
+
+int mbrl_model_dims(const mbrl_model *m, int *nq, int *nv, int *nu, double *dt) {
+    if (!m) return fail(-1, "mbrl_model_dims: null model");
+    if (nq) *nq = m->nq;
+    if (nv) *nv = m->nv;
+    if (nu) *nu = m->nu;
+    if (dt) *dt = m->timestep * m->frame_skip;
+    return 0;
+}
+
+int mbrl_step(const mbrl_model *m, int64_t N, const double *qpos, const double *qvel, const double *ctrl,
+              double *qpos_next, double *qvel_next, double *reward, uint32_t *status, void *hip_stream) {
+    if (!m) return fail(-1, "mbrl_step: null model");
+    if (N < 0) return fail(-6, "mbrl_step: negative N");
+    if (N == 0) return 0;
+    if (!qpos || !qvel || !ctrl || !qpos_next || !qvel_next) return fail(-1, "mbrl_step: null buffer");
+    if (N > (int64_t(1) << 31) * 64) return fail(-6, "mbrl_step: N too large");
+    if (hipSetDevice(m->device) != hipSuccess) return fail(-4, "mbrl_step: hipSetDevice failed");
+    hipStream_t st = (hipStream_t)hip_stream;
+    const unsigned blocks = (unsigned)((N + kBlock - 1) / kBlock);
+    MBRL_DISPATCH(m->env_id, hipLaunchKernelGGL((step_kernel<M>), dim3(blocks), dim3(kBlock), 0, st, N, m->frame_skip,
+                                                qpos, qvel, ctrl, qpos_next, qvel_next, reward, status));
+    return check_launch(m, "mbrl_step");
+}
+
+int mbrl_fd_jacobians(const mbrl_model *m, int64_t N, const double *qpos, const double *qvel, const double *ctrl,
+                      double eps, int fd_mode, int nsteps, double *dsds, double *dsda, double *drds, double *drda,
+                      double *s_next, double *reward, uint32_t *status, void *hip_stream) {
+    if (!m) return fail(-1, "mbrl_fd_jacobians: null model");
+    if (N < 0) return fail(-6, "mbrl_fd_jacobians: negative N");
+    if (N == 0) return 0;
+    if (!qpos || !qvel || !ctrl) return fail(-1, "mbrl_fd_jacobians: null input buffer");
+    if (!(eps > 0)) return fail(-7, "mbrl_fd_jacobians: eps must be > 0");
+    if (fd_mode != MBRL_FD_FORWARD && fd_mode != MBRL_FD_CENTRAL) return fail(-7, "mbrl_fd_jacobians: bad fd_mode");
+    if (nsteps <= 0) nsteps = 1;
+    if (N > (int64_t(1) << 31)) return fail(-6, "mbrl_fd_jacobians: N too large for one launch");
+    if (hipSetDevice(m->device) != hipSuccess) return fail(-4, "mbrl_fd_jacobians: hipSetDevice failed");
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (fd_mode == MBRL_FD_FORWARD) {
+        MBRL_DISPATCH(m->env_id, (launch_fd<M, false>(m, N, qpos, qvel, ctrl, eps, nsteps, dsds, dsda, drds, drda, s_next,
+                                                      reward, status, st)));
+    } else {
+        MBRL_DISPATCH(m->env_id, (launch_fd<M, true>(m, N, qpos, qvel, ctrl, eps, nsteps, dsds, dsda, drds, drda, s_next,
+                                                     reward, status, st)));
+    }
+    return check_launch(m, "mbrl_fd_jacobians");
+}
+
+int mbrl_vjp_scan(const mbrl_model *m, int64_t B, int H, int grad_weights, const double *dsds, const double *dsda,
+                  const double *drds, const double *drda, const double *c, double *da, double *ds0, void *hip_stream) {
+    if (!m) return fail(-1, "mbrl_vjp_scan: null model");
+    if (B < 0 || H < 0) return fail(-6, "mbrl_vjp_scan: negative size");
+    if (B == 0 || H == 0) return 0;
+    if (!dsds || !dsda || !drds || !drda || !c || !da) return fail(-1, "mbrl_vjp_scan: null buffer");
+    if (grad_weights < 0 || grad_weights > 2) return fail(-7, "mbrl_vjp_scan: bad grad_weights");
+    if (hipSetDevice(m->device) != hipSuccess) return fail(-4, "mbrl_vjp_scan: hipSetDevice failed");
+    const int per = kBlock / 32;
+    const unsigned blocks = (unsigned)((B + per - 1) / per);
+    hipLaunchKernelGGL(vjp_scan_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)hip_stream, B, H, m->nq + m->nv,
+                       m->nu, grad_weights, dsds, dsda, drds, drda, c, da, ds0);
+    return check_launch(m, "mbrl_vjp_scan");
+}
+
+}  // extern "C"

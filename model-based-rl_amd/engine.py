@@ -1,0 +1,92 @@
+"""Torch-facing wrapper of the C ABI: device tensors in, device tensors out.
+
+PyTorch is plumbing here (HBM allocation, streams); all arithmetic happens in the HIP
+kernels behind include/mbrl.h.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib, modelspec
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class FdEngine:
+    """One immutable model handle on one GPU (reference: build_agent, mujoco/build.py:6-37)."""
+
+    def __init__(self, env, frame_skip=0, device=None):
+        if env not in modelspec.MODELS:
+            raise KeyError("unknown MUJOCO.ENV %r" % (env,))
+        if not torch.cuda.is_available():
+            raise lib.MbrlError("no GPU visible: the FD path runs only on the HIP device (no CPU fallback)")
+        self.L = lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        h = C.c_void_p()
+        lib.check(self.L.mbrl_model_create(env.encode(), int(frame_skip), self.device.index or 0, C.byref(h)))
+        self.h = h
+        nq, nv, nu, dt = C.c_int(), C.c_int(), C.c_int(), C.c_double()
+        lib.check(self.L.mbrl_model_dims(h, nq, nv, nu, dt))
+        self.env, self.nq, self.nv, self.nu, self.dt = env, nq.value, nv.value, nu.value, dt.value
+        self.n = self.nq + self.nv
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            self.L.mbrl_model_destroy(h)
+
+    # ---- helpers ----
+    def _in(self, t, width):
+        t = torch.as_tensor(t, dtype=torch.float64, device=self.device)
+        if t.dim() == 1:
+            t = t.unsqueeze(0)
+        if t.shape[-1] != width:
+            raise ValueError("expected last dim %d, got %s" % (width, tuple(t.shape)))
+        return t.reshape(-1, width).contiguous()
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _new(self, *shape, dtype=torch.float64):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    # ---- entry points ----
+    def step(self, qpos, qvel, ctrl):
+        qpos, qvel, ctrl = self._in(qpos, self.nq), self._in(qvel, self.nv), self._in(ctrl, self.nu)
+        N = qpos.shape[0]
+        if qvel.shape[0] != N or ctrl.shape[0] != N:
+            raise ValueError("ragged batch")
+        qn, vn, r = self._new(N, self.nq), self._new(N, self.nv), self._new(N)
+        st = self._new(N, dtype=torch.int32)
+        with torch.cuda.device(self.device):
+            lib.check(self.L.mbrl_step(self.h, N, _ptr(qpos), _ptr(qvel), _ptr(ctrl), _ptr(qn), _ptr(vn), _ptr(r),
+                                       _ptr(st), self._stream()))
+        return qn, vn, r, st
+
+    def fd_jacobians(self, qpos, qvel, ctrl, eps=1e-6, fd_mode=lib.FD_FORWARD, nsteps=1, out=None):
+        qpos, qvel, ctrl = self._in(qpos, self.nq), self._in(qvel, self.nv), self._in(ctrl, self.nu)
+        N, n, nu = qpos.shape[0], self.n, self.nu
+        if qvel.shape[0] != N or ctrl.shape[0] != N:
+            raise ValueError("ragged batch")
+        o = out or dict(dsds=self._new(N, n, n), dsda=self._new(N, n, nu), drds=self._new(N, n),
+                        drda=self._new(N, nu), s_next=self._new(N, n), reward=self._new(N),
+                        status=self._new(N, dtype=torch.int32))
+        with torch.cuda.device(self.device):
+            lib.check(self.L.mbrl_fd_jacobians(self.h, N, _ptr(qpos), _ptr(qvel), _ptr(ctrl), float(eps),
+                                               int(fd_mode), int(nsteps), _ptr(o["dsds"]), _ptr(o["dsda"]),
+                                               _ptr(o["drds"]), _ptr(o["drda"]), _ptr(o["s_next"]),
+                                               _ptr(o["reward"]), _ptr(o["status"]), self._stream()))
+        return o
+
+    def vjp_scan(self, jac, c, grad_weights="average"):
+        """Backward recurrence over [B, H] stored Jacobians (index b*H + t); c = dL/dreward [B, H]."""
+        gw = {"none": 0, "average": 1, "prioritise": 2}.get(grad_weights, 0)
+        c = torch.as_tensor(c, dtype=torch.float64, device=self.device).contiguous()
+        B, H = c.shape
+        da, ds0 = self._new(B, H, self.nu), self._new(B, self.n)
+        with torch.cuda.device(self.device):
+            lib.check(self.L.mbrl_vjp_scan(self.h, B, H, gw, _ptr(jac["dsds"]), _ptr(jac["dsda"]), _ptr(jac["drds"]),
+                                           _ptr(jac["drda"]), _ptr(c), _ptr(da), _ptr(ds0), self._stream()))
+        return da, ds0

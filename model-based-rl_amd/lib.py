@@ -1,0 +1,52 @@
+"""ctypes binding of the C ABI in include/mbrl.h (csrc/libmbrl_hip.so).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is visible, loading /
+model creation raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libmbrl_hip.so")
+
+ST_NONFINITE, ST_NOCONVERGE, ST_OVERFLOW = 1, 2, 4
+FD_FORWARD, FD_CENTRAL = 0, 1
+
+SYMBOLS = ("mbrl_abi_version", "mbrl_model_create", "mbrl_model_destroy", "mbrl_model_dims", "mbrl_step",
+           "mbrl_fd_jacobians", "mbrl_vjp_scan", "mbrl_last_error")
+
+_lib = None
+vp = C.c_void_p
+
+
+class MbrlError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MbrlError("HIP extension not built: %s is missing (run __graft_entry__.build()); "
+                        "this package has no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.mbrl_abi_version.restype = C.c_int
+    L.mbrl_last_error.restype = C.c_char_p
+    L.mbrl_model_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
+    L.mbrl_model_destroy.argtypes = [vp]
+    L.mbrl_model_destroy.restype = None
+    L.mbrl_model_dims.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                  C.POINTER(C.c_double)]
+    L.mbrl_step.argtypes = [vp, C.c_int64] + [vp] * 7 + [vp]
+    L.mbrl_fd_jacobians.argtypes = [vp, C.c_int64, vp, vp, vp, C.c_double, C.c_int, C.c_int] + [vp] * 7 + [vp]
+    L.mbrl_vjp_scan.argtypes = [vp, C.c_int64, C.c_int, C.c_int] + [vp] * 7 + [vp]
+    if L.mbrl_abi_version() != 1:
+        raise MbrlError("ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise MbrlError("%s (code %d)" % (load().mbrl_last_error().decode(), rc))
