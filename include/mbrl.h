@@ -29,6 +29,7 @@ extern "C" {
 #define MBRL_ST_NONFINITE  1u  /* NaN/Inf state or non-positive pivot */
 #define MBRL_ST_NOCONVERGE 2u  /* constraint solver hit its iteration cap */
 #define MBRL_ST_OVERFLOW   4u  /* reserved (contact capacity) */
+#define MBRL_ST_DEGENERATE 8u  /* two capsule axes cross (distance 0): that contact's normal is undefined */
 
 #define MBRL_FD_FORWARD 0      /* reference parity: one-sided, (f(x+eps)-f(x))/eps, backward.py:402-406 */
 #define MBRL_FD_CENTRAL 1      /* (f(x+eps)-f(x-eps))/(2 eps) */

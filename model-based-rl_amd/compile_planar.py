@@ -281,6 +281,28 @@ class PlanarModel:
             self.c_solimp.append(clamp_solimp(solimp))
             self.c_RK.append(RK)
         self.selfcollide = bool(m["selfcollide"])
+        # capsule-capsule pairs (Hopper): same-body and parent-child (parent != world) pairs are filtered
+        self.pairs = []
+        if self.selfcollide:
+            for g1 in range(self.NG):
+                for g2 in range(g1 + 1, self.NG):
+                    b1, b2 = self.g_body[g1], self.g_body[g2]
+                    if b1 == b2 or self.parent[b2] == b1 or self.parent[b1] == b2:
+                        continue
+                    G1, G2 = self.g_raw[g1], self.g_raw[g2]
+                    if not ((G1["contype"] & G2["conaffinity"]) or (G2["contype"] & G1["conaffinity"])):
+                        continue
+                    bb = b2
+                    while bb >= 0 and bb != b1:
+                        bb = self.parent[bb]
+                    assert bb == b1, "pair rows assume geom1's body is an ancestor of geom2's body"
+                    assert max(G1["condim"], G2["condim"]) == 1, "body-body contacts are frictionless here"
+                    solref = tuple(0.5 * (x + y) for x, y in zip(G1["solref"], G2["solref"]))
+                    solimp = tuple(0.5 * (x + y) for x, y in zip(G1["solimp"], G2["solimp"]))
+                    K, Bd = ref_kb(solref, solimp, m["timestep"])
+                    self.pairs.append(dict(g1=g1, g2=g2, margin=max(G1["margin"], G2["margin"]), K=K, B=Bd,
+                                           solimp=clamp_solimp(solimp),
+                                           RK=self.body_invweight0[b1][0] + self.body_invweight0[b2][0]))
 
     def _fluid(self):
         m = self.spec
@@ -382,6 +404,15 @@ def emit_model(pm, cname):
         A("  static constexpr double c_B[NG] = %s;" % _arr(pm.c_B))
         A("  static constexpr double c_RK[NG] = %s;" % _arr(pm.c_RK))
         A("  static constexpr double c_solimp[NG][5] = %s;" % _arr2(pm.c_solimp))
+    prs = pm.pairs or [dict(g1=0, g2=0, margin=0.0, K=0.0, B=0.0, solimp=modelspec.SOLIMP0, RK=0.0)]
+    A("  static constexpr int NPAIR = %d;" % len(pm.pairs))
+    A("  static constexpr int pair_g1[%d] = %s, pair_g2[%d] = %s;" % (
+        len(prs), _arr([p["g1"] for p in prs], str), len(prs), _arr([p["g2"] for p in prs], str)))
+    A("  static constexpr double pair_margin[%d] = %s;" % (len(prs), _arr([p["margin"] for p in prs])))
+    A("  static constexpr double pair_K[%d] = %s;" % (len(prs), _arr([p["K"] for p in prs])))
+    A("  static constexpr double pair_B[%d] = %s;" % (len(prs), _arr([p["B"] for p in prs])))
+    A("  static constexpr double pair_RK[%d] = %s;" % (len(prs), _arr([p["RK"] for p in prs])))
+    A("  static constexpr double pair_solimp[%d][5] = %s;" % (len(prs), _arr2([p["solimp"] for p in prs])))
     A("  static constexpr double fl_kv_lin[NB] = %s;" % _arr([f["kv_lin"] for f in pm.fl]))
     A("  static constexpr double fl_kv_ang[NB] = %s;" % _arr([f["kv_ang"] for f in pm.fl]))
     A("  static constexpr double fl_kq_a[NB] = %s;" % _arr([f["kq_a"] for f in pm.fl]))

@@ -39,7 +39,7 @@
 namespace mbrl {
 
 constexpr double kMinVal = 1e-15;
-constexpr unsigned ST_NONFINITE = 1u, ST_NOCONVERGE = 2u, ST_OVERFLOW = 4u;
+constexpr unsigned ST_NONFINITE = 1u, ST_NOCONVERGE = 2u, ST_OVERFLOW = 4u, ST_DEGENERATE = 8u;
 constexpr int kMaxNewton = 100;
 constexpr int kMaxLineSearch = 40;
 
@@ -98,6 +98,9 @@ struct Sim {
     uint64_t lim_on, con_on;             // active candidates (bit j / bit c)
     T lsg[NV], lD[NV], laref[NV];        // limit rows: J = lsg (+-1) on dof j
     T cpa[NC], cpb[NC], cD[NC], can[NC], cat[NC];  // contact point rel. O, D, aref (normal / tangent parts)
+    static constexpr int NPR = M::NPAIR > 0 ? M::NPAIR : 1;
+    uint64_t pair_on;                    // active capsule-capsule pairs
+    T pw0[NPR], pw1[NPR], pw2[NPR], pD[NPR], paref[NPR];  // row = w . (V_b2 - V_b1)
     T site_a, site_b;
     unsigned status;
     int newton_iters;
@@ -247,7 +250,7 @@ struct Sim {
 
     // constraint candidates: joint limits and capsule-end/plane contacts; needs kinematics(), v
     MBRL_HD void make_constraints() {
-        lim_on = 0; con_on = 0;
+        lim_on = 0; con_on = 0; pair_on = 0;
         MBRL_UNROLL
         for (int j = 0; j < NV; j++) {
             if (!M::limited[j]) continue;
@@ -263,9 +266,52 @@ struct Sim {
                 lim_on |= (uint64_t(1) << j);
             }
         }
-        if (!M::HAS_FLOOR) return;
+        if (!M::HAS_FLOOR && M::NPAIR == 0) return;
         Sp<T> V[NB];
         bool haveV = false;
+        MBRL_UNROLL
+        for (int k = 0; k < M::NPAIR; k++) {
+            // capsule-capsule: closest points of the two axis segments, then sphere-sphere
+            const int g1 = M::pair_g1[k], g2 = M::pair_g2[k], b1 = M::g_body[g1], b2 = M::g_body[g2];
+            const T p1a = pa[b1] + (c[b1] * M::g_ea[g1][0] - s[b1] * M::g_ea[g1][1]);
+            const T p1b = pb[b1] + (s[b1] * M::g_ea[g1][0] + c[b1] * M::g_ea[g1][1]);
+            const T q1a = pa[b1] + (c[b1] * M::g_eb[g1][0] - s[b1] * M::g_eb[g1][1]);
+            const T q1b = pb[b1] + (s[b1] * M::g_eb[g1][0] + c[b1] * M::g_eb[g1][1]);
+            const T p2a = pa[b2] + (c[b2] * M::g_ea[g2][0] - s[b2] * M::g_ea[g2][1]);
+            const T p2b = pb[b2] + (s[b2] * M::g_ea[g2][0] + c[b2] * M::g_ea[g2][1]);
+            const T q2a = pa[b2] + (c[b2] * M::g_eb[g2][0] - s[b2] * M::g_eb[g2][1]);
+            const T q2b = pb[b2] + (s[b2] * M::g_eb[g2][0] + c[b2] * M::g_eb[g2][1]);
+            const T d1a = q1a - p1a, d1b = q1b - p1b, d2a = q2a - p2a, d2b = q2b - p2b;
+            const T rra = p1a - p2a, rrb = p1b - p2b;
+            const T aa = d1a * d1a + d1b * d1b, ee = d2a * d2a + d2b * d2b, ff = d2a * rra + d2b * rrb;
+            const T cc = d1a * rra + d1b * rrb, bb = d1a * d2a + d1b * d2b;
+            const T den = aa * ee - bb * bb;
+            T ss = (t_val(den) < 1e-12 * t_val(aa) * t_val(ee)) ? T(0.0) : (bb * ff - cc * ee) / den;
+            ss = t_min(T(1.0), t_max(T(0.0), ss));
+            T tt = (bb * ss + ff) / ee;
+            if (t_val(tt) < 0.0) { tt = T(0.0); ss = t_min(T(1.0), t_max(T(0.0), -cc / aa)); }
+            else if (t_val(tt) > 1.0) { tt = T(1.0); ss = t_min(T(1.0), t_max(T(0.0), (bb - cc) / aa)); }
+            const T c1a = p1a + ss * d1a, c1b = p1b + ss * d1b, c2a = p2a + tt * d2a, c2b = p2b + tt * d2b;
+            const T dfa = c2a - c1a, dfb = c2b - c1b;
+            const T len = t_sqrt(dfa * dfa + dfb * dfb);
+            const T dist = len - M::g_rad[g1] - M::g_rad[g2];
+            if (t_val(dist) < M::pair_margin[k]) {
+                if (!haveV) { vel_pass(v, V); haveV = true; }
+                if (t_val(len) < 1e-10) status |= ST_DEGENERATE;  // crossing axes: normal is round-off noise
+                T na = T(1.0), nb = T(0.0);
+                if (!(t_val(len) < kMinVal)) { na = dfa / len; nb = dfb / len; }
+                const T Pa = c1a + na * (M::g_rad[g1] + T(0.5) * dist);
+                const T Pb = c1b + nb * (M::g_rad[g1] + T(0.5) * dist);
+                const T pm = dist - M::pair_margin[k];
+                const T imp = impedance(M::pair_solimp[k], pm);
+                const T R = t_max(T(kMinVal), (T(1.0) - imp) * M::pair_RK[k] / imp);
+                pw0[k] = nb * Pa - na * Pb; pw1[k] = na; pw2[k] = nb; pD[k] = T(1.0) / R;
+                const T vel = pw0[k] * (V[b2].w - V[b1].w) + pw1[k] * (V[b2].a - V[b1].a) + pw2[k] * (V[b2].b - V[b1].b);
+                paref[k] = -M::pair_B[k] * vel - M::pair_K[k] * imp * pm;
+                pair_on |= (uint64_t(1) << k);
+            }
+        }
+        if (!M::HAS_FLOOR) return;
         MBRL_UNROLL
         for (int g = 0; g < M::NGEOM; g++) {
             if (!M::c_on[g]) continue;
@@ -449,6 +495,14 @@ struct Sim {
             if (!M::limited[j]) continue;
             if (lim_on & (uint64_t(1) << j)) fn.limit(j, lsg[j] * x[j]);
         }
+        MBRL_UNROLL
+        for (int k = 0; k < M::NPAIR; k++) {
+            if (pair_on & (uint64_t(1) << k)) {
+                const int b1 = M::g_body[M::pair_g1[k]], b2 = M::g_body[M::pair_g2[k]];
+                fn.pair(k, b1, b2, pw0[k] * (Va[b2].w - Va[b1].w) + pw1[k] * (Va[b2].a - Va[b1].a) +
+                                       pw2[k] * (Va[b2].b - Va[b1].b));
+            }
+        }
         if (!M::HAS_FLOOR) return;
         MBRL_UNROLL
         for (int g = 0; g < M::NGEOM; g++) {
@@ -491,6 +545,15 @@ struct Sim {
                 }
             }
         }
+        MBRL_HD void pair(int k, int b1, int b2, T vrel) {
+            const T jar = vrel - S->paref[k];
+            if (t_val(jar) < 0.0) {
+                mask |= uint64_t(1) << (NV + 3 * NC + k);
+                const T f = -S->pD[k] * jar;
+                Fc[b2].w = Fc[b2].w + f * S->pw0[k]; Fc[b2].a = Fc[b2].a + f * S->pw1[k]; Fc[b2].b = Fc[b2].b + f * S->pw2[k];
+                Fc[b1].w = Fc[b1].w - f * S->pw0[k]; Fc[b1].a = Fc[b1].a - f * S->pw1[k]; Fc[b1].b = Fc[b1].b - f * S->pw2[k];
+            }
+        }
         MBRL_HD void contact(int g, int ci, int b, T vn, T vt) {
             const T rn = vn - S->can[ci], rt = vt - S->cat[ci];
             if (M::c_dim[g] == 1) { row(ci, b, 2, rn, T(1.0), T(0.0), T(1.0)); return; }
@@ -508,6 +571,11 @@ struct Sim {
             if (t_val(r) < 0.0) { mask |= uint64_t(1) << bit; g = g + D * r * jv; h = h + D * jv * jv; }
         }
         MBRL_HD void limit(int j, T jx) { acc(j, jx - S->laref[j], S->lsg[j] * sx[j], S->lD[j]); }
+        MBRL_HD void pair(int k, int b1, int b2, T vrel) {
+            const T sv = S->pw0[k] * (Vs[b2].w - Vs[b1].w) + S->pw1[k] * (Vs[b2].a - Vs[b1].a) +
+                         S->pw2[k] * (Vs[b2].b - Vs[b1].b);
+            acc(NV + 3 * NC + k, vrel - S->paref[k], sv, S->pD[k]);
+        }
         MBRL_HD void contact(int gi, int ci, int b, T vn, T vt) {
             const T rn = vn - S->can[ci], rt = vt - S->cat[ci];
             const T sn = Vs[b].b + Vs[b].w * S->cpa[ci], st = Vs[b].a - Vs[b].w * S->cpb[ci];
@@ -524,7 +592,7 @@ struct Sim {
         MBRL_UNROLL
         for (int j = 0; j < NV; j++) { qacc[j] = qs[j]; fcon[j] = T(0.0); }
         newton_iters = 0;
-        if (lim_on == 0 && con_on == 0) return;
+        if (lim_on == 0 && con_on == 0 && pair_on == 0) return;
         uint64_t prev = ~uint64_t(0);
         bool converged = false;
         T arm[NV];
@@ -563,6 +631,29 @@ struct Sim {
             back_pass(Fm, Ma);
             T H[NV][NV];
             crba(Ic, H, hdiag);
+            MBRL_UNROLL
+            for (int k = 0; k < M::NPAIR; k++) {
+                // a pair row couples two bodies: explicit D r r^T on the dofs between them (b1 is an ancestor of b2)
+                if (gp.mask & (uint64_t(1) << (NV + 3 * NC + k))) {
+                    const int b1 = M::g_body[M::pair_g1[k]], b2 = M::g_body[M::pair_g2[k]];
+                    T rr[NV];
+                    MBRL_UNROLL
+                    for (int j = 0; j < NV; j++) {
+                        if (!(TP::body_anc(M::dof_body[j], b2) && !TP::body_anc(M::dof_body[j], b1))) continue;
+                        const Sp<T> Sj = Scol(j);
+                        rr[j] = pw0[k] * Sj.w + pw1[k] * Sj.a + pw2[k] * Sj.b;
+                    }
+                    MBRL_UNROLL
+                    for (int i = 0; i < NV; i++) {
+                        if (!(TP::body_anc(M::dof_body[i], b2) && !TP::body_anc(M::dof_body[i], b1))) continue;
+                        MBRL_UNROLL
+                        for (int j = 0; j <= i; j++) {
+                            if (!(TP::body_anc(M::dof_body[j], b2) && !TP::body_anc(M::dof_body[j], b1))) continue;
+                            H[i][j] = H[i][j] + pD[k] * rr[i] * rr[j];
+                        }
+                    }
+                }
+            }
             const bool ok = factor(H);
             if (!ok) { status |= ST_NONFINITE; break; }
             T gnorm = T(0.0), a1 = T(0.0);

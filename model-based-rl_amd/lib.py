@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libmbrl_hip.so")
 
-ST_NONFINITE, ST_NOCONVERGE, ST_OVERFLOW = 1, 2, 4
+ST_NONFINITE, ST_NOCONVERGE, ST_OVERFLOW, ST_DEGENERATE = 1, 2, 4, 8
 FD_FORWARD, FD_CENTRAL = 0, 1
 
 SYMBOLS = ("mbrl_abi_version", "mbrl_model_create", "mbrl_model_destroy", "mbrl_model_dims", "mbrl_step",
@@ -30,6 +30,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise MbrlError("HIP extension not built: %s is missing (run __graft_entry__.build()); "
                         "this package has no CPU fallback" % LIB_PATH)
+    # torch ships its own HIP runtime (libamdhip64): load it FIRST so that this library binds to the
+    # same runtime instance as torch's streams/allocations instead of a second copy from /opt/rocm.
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     L.mbrl_abi_version.restype = C.c_int
     L.mbrl_last_error.restype = C.c_char_p

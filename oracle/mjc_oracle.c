@@ -386,6 +386,7 @@ static void sphereSphere(Data *d, const Contact *proto, const double *c1, double
     double dist = len - r1 - r2;
     if (dist >= proto->includemargin) return;
     Contact c = *proto;
+    if (len < 1e-10) d->status |= MJO_ST_DEGENERATE; /* crossing axes: the normal is round-off noise */
     if (len < MINVAL) { c.frame[0] = 1; c.frame[1] = 0; c.frame[2] = 0; }
     else for (int k = 0; k < 3; k++) c.frame[k] = dif[k] / len;
     for (int k = 0; k < 3; k++) c.pos[k] = c1[k] + c.frame[k] * (r1 + 0.5 * dist);

