@@ -148,7 +148,7 @@ def main():
                        "parallelism": "units sharded over %d GPU(s), no data-path collective" % world},
             "roofline": {"bound": "valu_fp64", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "fd_kernel<MdlHalfCheetah>", "kernel_ms": kern_ms,
+                         "kernel": "rollout_kernel<MdlHalfCheetah>", "kernel_ms": kern_ms,
                          "flops_per_unit": fpu, "flops_source": how,
                          "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                  "bytes_per_unit": bytes_unit},

@@ -8,7 +8,7 @@ from . import compile_planar
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libmbrl_hip.so")
-SOURCES = ["mbrl_hip.hip", "planar_sim.hpp", "models_gen.hpp"]
+SOURCES = ["mbrl_hip.hip", "planar_lean.hpp", "models_gen.hpp"]
 
 
 def _hipcc():
@@ -33,7 +33,7 @@ def build_hip(force=False, verbose=False):
     compile_planar.write_header()
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed",
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed", "-mllvm", "-pragma-unroll-threshold=1000000",
            "-o", LIB + ".tmp", os.path.join(CSRC, "mbrl_hip.hip")]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

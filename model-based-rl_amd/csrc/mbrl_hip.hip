@@ -7,8 +7,10 @@
 //   * a 256-thread workgroup owns UPB = 256 / R whole units; rollout results meet in LDS and the
 //     workgroup writes that block of Jacobians with fully coalesced stores (the outputs of
 //     consecutive units are contiguous in every output array);
-//   * the path is fp64-VALU bound (~1 MFLOP per HalfCheetah unit vs 4 KB of HBM traffic), so the
-//     per-lane simulator (planar_sim.hpp) keeps its whole working set in registers.
+//   * the path is fp64-VALU bound (~1 MFLOP per HalfCheetah unit vs 4 KB of HBM traffic); the per-lane
+//     simulator (planar_lean.hpp) keeps its hot working set in registers and its cold / lane-indexed
+//     state (q, v, ctrl, active limit and contact rows) in a lane-interleaved LDS column, which the
+//     result staging buffer re-uses once the rollouts are done.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -17,80 +19,90 @@
 #include <new>
 
 #include "../../include/mbrl.h"
-#include "planar_sim.hpp"
+#include "planar_lean.hpp"
 
 namespace mbrl {
 
 constexpr int kBlock = 256;
 
-template <class M, bool CENTRAL>
-struct FdShape {
-    static constexpr int NP = M::NU + 2 * M::NV;                 // perturbed inputs
-    static constexpr int R = CENTRAL ? 1 + 2 * NP : 1 + NP;     // rollouts per unit
-    static constexpr int UPB = kBlock / R;                      // units per workgroup
-    static constexpr int NS = 2 * M::NV;                        // state size n
-    static constexpr int ROW = NS + 1;                          // s' and reward
-};
+constexpr int MODE_FORWARD = 0, MODE_CENTRAL = 1, MODE_STEP = 2;
 
-// column order of calculate_gradients: ctrl, then qvel, then qpos (backward.py:389,409,433)
-template <class M, bool CENTRAL>
-__global__ __launch_bounds__(kBlock) void fd_kernel(int64_t N, int frame_skip, int nsteps, double eps,
-                                                     const double *__restrict__ qpos,
-                                                     const double *__restrict__ qvel,
-                                                     const double *__restrict__ ctrl, double *__restrict__ dsds,
-                                                     double *__restrict__ dsda, double *__restrict__ drds,
-                                                     double *__restrict__ drda, double *__restrict__ s_next,
-                                                     double *__restrict__ reward, uint32_t *__restrict__ status) {
-    using Sh = FdShape<M, CENTRAL>;
-    constexpr int NV = M::NV, NU = M::NU, NS = Sh::NS, R = Sh::R, UPB = Sh::UPB, ROW = Sh::ROW;
-    __shared__ double res[UPB * R * ROW];
-    __shared__ unsigned stat[UPB];
+// ONE kernel per model for env.step, forward-difference and central-difference linearisation: the
+// mode is a run-time argument, so the nominal rollout of an FD launch and a plain step launch execute
+// the same machine code and agree bit for bit (the reference asserts exactly that, backward.py:371,374).
+//   mode FORWARD: R = 1 + NP rollouts per unit (NP = nu + nv + nq), CENTRAL: R = 1 + 2 NP, STEP: R = 1.
+// Column order of calculate_gradients: ctrl, then qvel, then qpos (backward.py:389,409,433).
+template <class M>
+__global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_skip, int nsteps, double eps, int mode,
+                                                          const double *__restrict__ qpos,
+                                                          const double *__restrict__ qvel,
+                                                          const double *__restrict__ ctrl, double *__restrict__ dsds,
+                                                          double *__restrict__ dsda, double *__restrict__ drds,
+                                                          double *__restrict__ drda, double *__restrict__ s_next,
+                                                          double *__restrict__ qpos_next, double *__restrict__ qvel_next,
+                                                          double *__restrict__ reward, uint32_t *__restrict__ status) {
+    using LY = Layout<M>;
+    constexpr int NV = M::NV, NU = M::NU, NS = 2 * NV, ROW = NS + 1, NP = NU + 2 * NV;
+    static_assert(LY::NMEM >= ROW, "the staging buffer re-uses the lane columns");
+    static_assert(1 + 2 * NP <= kBlock, "a unit's rollouts must fit one workgroup");
+    __shared__ double lds[LY::NMEM * kBlock];   // lane columns during the rollouts, then res[UPB*R][ROW]
+    __shared__ unsigned stat[kBlock];
+    double *res = lds;
 
+    const bool central = mode == MODE_CENTRAL;
+    const int R = mode == MODE_STEP ? 1 : (central ? 1 + 2 * NP : 1 + NP);   // rollouts per unit
+    const int UPB = kBlock / R;                                              // units per workgroup
     const int t = threadIdx.x;
     const int u = t / R, p = t - u * R;
     const int64_t unit0 = int64_t(blockIdx.x) * UPB;
     const int64_t unit = unit0 + u;
-    if (t < UPB) stat[t] = 0;
+    stat[t] = 0;
     __syncthreads();
 
-    if (u < UPB && unit < N) {
-        Sim<M, double> S;
+    const bool live = u < UPB && unit < N;
+    double o[ROW];
+    unsigned st = 0;
+    if (live) {
+        Lean<M, double, LaneMem<double, kBlock>> S;
         S.status = 0;
+        S.mem.p = lds + t;
         const double *qp = qpos + unit * NV, *vp = qvel + unit * NV, *cp = ctrl + unit * NU;
-#pragma unroll
-        for (int j = 0; j < NV; j++) { S.q[j] = qp[j]; S.v[j] = vp[j]; }
-#pragma unroll
-        for (int k = 0; k < NU; k++) S.ctrl[k] = cp[k];
+        int idx = -1;
+        double d = eps;
         if (p > 0) {
-            int idx = p - 1;
-            double d = eps;
-            if (CENTRAL) { d = (idx & 1) ? -eps : eps; idx >>= 1; }
-            // static indexing only: scan the inputs instead of indexing a register array
-#pragma unroll
-            for (int k = 0; k < NU; k++) if (idx == k) S.ctrl[k] += d;
-#pragma unroll
-            for (int j = 0; j < NV; j++) if (idx == NU + j) S.v[j] += d;
-#pragma unroll
-            for (int j = 0; j < NV; j++) if (idx == NU + NV + j) S.q[j] += d;
+            idx = p - 1;
+            if (central) { d = (idx & 1) ? -eps : eps; idx >>= 1; }
         }
+#pragma unroll
+        for (int k = 0; k < NU; k++) S.mem.st(LY::OC + k, idx == k ? cp[k] + d : cp[k]);
+#pragma unroll
+        for (int j = 0; j < NV; j++) S.mem.st(LY::OV + j, idx == NU + j ? vp[j] + d : vp[j]);
+#pragma unroll
+        for (int j = 0; j < NV; j++) S.mem.st(LY::OQ + j, idx == NU + NV + j ? qp[j] + d : qp[j]);
         double r = 0.0;
         for (int k = 0; k < nsteps; k++) r = S.env_step(frame_skip);
         S.check_finite();
-        double *o = res + (u * R + p) * ROW;
 #pragma unroll
-        for (int j = 0; j < NV; j++) { o[j] = S.q[j]; o[NV + j] = S.v[j]; }
+        for (int j = 0; j < NV; j++) { o[j] = S.mem.ld(LY::OQ + j); o[NV + j] = S.mem.ld(LY::OV + j); }
         o[NS] = r;
-        if (S.status) atomicOr(&stat[u], S.status);
+        st = S.status;
+    }
+    __syncthreads();                      // every lane is done with its column: re-use LDS as res
+    if (live) {
+        double *ro = res + (u * R + p) * ROW;
+#pragma unroll
+        for (int j = 0; j < ROW; j++) ro[j] = o[j];
+        if (st) atomicOr(&stat[u], st);
     }
     __syncthreads();
 
     int64_t nun = N - unit0;
     if (nun > UPB) nun = UPB;
     const int nu_blk = int(nun);
-    const double den = CENTRAL ? 2.0 * eps : eps;
-    // perturbation slot of input column `in` (0..NU+2NV-1 in ctrl,qvel,qpos order)
-    auto plus = [](int in) { return CENTRAL ? 1 + 2 * in : 1 + in; };
-    auto minus = [](int in) { return CENTRAL ? 2 + 2 * in : 0; };
+    const double den = central ? 2.0 * eps : eps;
+    // perturbation slot of input column `in` (0..NP-1 in ctrl,qvel,qpos order)
+    auto plus = [central](int in) { return central ? 1 + 2 * in : 1 + in; };
+    auto minus = [central](int in) { return central ? 2 + 2 * in : 0; };
 
     if (dsds) {  // [unit][o][col], col < NV: qpos input, else qvel input
         double *base = dsds + unit0 * NS * NS;
@@ -133,34 +145,18 @@ __global__ __launch_bounds__(kBlock) void fd_kernel(int64_t N, int frame_skip, i
             base[e] = res[uu * R * ROW + o];
         }
     }
+    if (qpos_next) {   // split form of s_next (mbrl_step)
+        double *bq = qpos_next + unit0 * NV, *bv = qvel_next + unit0 * NV;
+        for (int e = t; e < nu_blk * NV; e += kBlock) {
+            const int uu = e / NV, o = e - uu * NV;
+            bq[e] = res[uu * R * ROW + o];
+            bv[e] = res[uu * R * ROW + NV + o];
+        }
+    }
     if (t < nu_blk) {
         if (reward) reward[unit0 + t] = res[t * R * ROW + NS];
         if (status) status[unit0 + t] = stat[t];
     }
-}
-
-template <class M>
-__global__ __launch_bounds__(kBlock) void step_kernel(int64_t N, int frame_skip, const double *__restrict__ qpos,
-                                                       const double *__restrict__ qvel,
-                                                       const double *__restrict__ ctrl,
-                                                       double *__restrict__ qpos_next,
-                                                       double *__restrict__ qvel_next, double *__restrict__ reward,
-                                                       uint32_t *__restrict__ status) {
-    constexpr int NV = M::NV, NU = M::NU;
-    const int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x;
-    if (i >= N) return;
-    Sim<M, double> S;
-    S.status = 0;
-#pragma unroll
-    for (int j = 0; j < NV; j++) { S.q[j] = qpos[i * NV + j]; S.v[j] = qvel[i * NV + j]; }
-#pragma unroll
-    for (int k = 0; k < NU; k++) S.ctrl[k] = ctrl[i * NU + k];
-    const double r = S.env_step(frame_skip);
-    S.check_finite();
-#pragma unroll
-    for (int j = 0; j < NV; j++) { qpos_next[i * NV + j] = S.q[j]; qvel_next[i * NV + j] = S.v[j]; }
-    if (reward) reward[i] = r;
-    if (status) status[i] = S.status;
 }
 
 // Backward recurrence of the op chain (mujoco.py:43-104): one thread per (episode, output lane).
@@ -250,15 +246,17 @@ static int check_launch(const mbrl_model *m, const char *what) {
     return 0;
 }
 
-template <class M, bool CENTRAL>
-static void launch_fd(const mbrl_model *m, int64_t N, const double *qpos, const double *qvel, const double *ctrl,
-                      double eps, int nsteps, double *dsds, double *dsda, double *drds, double *drda,
-                      double *s_next, double *reward, uint32_t *status, hipStream_t st) {
-    using Sh = FdShape<M, CENTRAL>;
-    static_assert(Sh::UPB >= 1, "a unit's rollouts must fit one workgroup");
-    const int64_t blocks = (N + Sh::UPB - 1) / Sh::UPB;
-    hipLaunchKernelGGL((fd_kernel<M, CENTRAL>), dim3((unsigned)blocks), dim3(kBlock), 0, st, N, m->frame_skip, nsteps,
-                       eps, qpos, qvel, ctrl, dsds, dsda, drds, drda, s_next, reward, status);
+template <class M>
+static void launch_rollouts(const mbrl_model *m, int64_t N, int mode, const double *qpos, const double *qvel,
+                            const double *ctrl, double eps, int nsteps, double *dsds, double *dsda, double *drds,
+                            double *drda, double *s_next, double *qpos_next, double *qvel_next, double *reward,
+                            uint32_t *status, hipStream_t st) {
+    constexpr int NP = M::NU + 2 * M::NV;
+    const int R = mode == MODE_STEP ? 1 : (mode == MODE_CENTRAL ? 1 + 2 * NP : 1 + NP);
+    const int upb = kBlock / R;
+    const int64_t blocks = (N + upb - 1) / upb;
+    hipLaunchKernelGGL((rollout_kernel<M>), dim3((unsigned)blocks), dim3(kBlock), 0, st, N, m->frame_skip, nsteps, eps,
+                       mode, qpos, qvel, ctrl, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward, status);
 }
 
 extern "C" {
@@ -302,12 +300,11 @@ int mbrl_step(const mbrl_model *m, int64_t N, const double *qpos, const double *
     if (N < 0) return fail(-6, "mbrl_step: negative N");
     if (N == 0) return 0;
     if (!qpos || !qvel || !ctrl || !qpos_next || !qvel_next) return fail(-1, "mbrl_step: null buffer");
-    if (N > (int64_t(1) << 31) * 64) return fail(-6, "mbrl_step: N too large");
+    if (N > (int64_t(1) << 31)) return fail(-6, "mbrl_step: N too large for one launch");
     if (hipSetDevice(m->device) != hipSuccess) return fail(-4, "mbrl_step: hipSetDevice failed");
     hipStream_t st = (hipStream_t)hip_stream;
-    const unsigned blocks = (unsigned)((N + kBlock - 1) / kBlock);
-    MBRL_DISPATCH(m->env_id, hipLaunchKernelGGL((step_kernel<M>), dim3(blocks), dim3(kBlock), 0, st, N, m->frame_skip,
-                                                qpos, qvel, ctrl, qpos_next, qvel_next, reward, status));
+    MBRL_DISPATCH(m->env_id, (launch_rollouts<M>(m, N, MODE_STEP, qpos, qvel, ctrl, 0.0, 1, nullptr, nullptr, nullptr,
+                                                 nullptr, nullptr, qpos_next, qvel_next, reward, status, st)));
     return check_launch(m, "mbrl_step");
 }
 
@@ -324,13 +321,9 @@ int mbrl_fd_jacobians(const mbrl_model *m, int64_t N, const double *qpos, const 
     if (N > (int64_t(1) << 31)) return fail(-6, "mbrl_fd_jacobians: N too large for one launch");
     if (hipSetDevice(m->device) != hipSuccess) return fail(-4, "mbrl_fd_jacobians: hipSetDevice failed");
     hipStream_t st = (hipStream_t)hip_stream;
-    if (fd_mode == MBRL_FD_FORWARD) {
-        MBRL_DISPATCH(m->env_id, (launch_fd<M, false>(m, N, qpos, qvel, ctrl, eps, nsteps, dsds, dsda, drds, drda, s_next,
-                                                      reward, status, st)));
-    } else {
-        MBRL_DISPATCH(m->env_id, (launch_fd<M, true>(m, N, qpos, qvel, ctrl, eps, nsteps, dsds, dsda, drds, drda, s_next,
-                                                     reward, status, st)));
-    }
+    MBRL_DISPATCH(m->env_id, (launch_rollouts<M>(m, N, fd_mode == MBRL_FD_CENTRAL ? MODE_CENTRAL : MODE_FORWARD, qpos, qvel,
+                                                 ctrl, eps, nsteps, dsds, dsda, drds, drda, s_next, nullptr, nullptr,
+                                                 reward, status, st)));
     return check_launch(m, "mbrl_fd_jacobians");
 }
 

@@ -1,0 +1,942 @@
+// planar_lean.hpp -- per-lane planar rigid-body simulator of the HIP kernels (register-lean form).
+//
+// One instance = one rollout (one lane).  Templated on a compile-time model table
+// (models_gen.hpp): after full unrolling every register-array index is a constant.  What it
+// computes is the arithmetic the reference reaches through mujoco-py:
+// MuJoCo 2.0 `mj_step` for planar hinge/slide trees --
+//   kinematics -> recursive Newton-Euler bias -> passive (spring, damper, inertia-box fluid) ->
+//   actuation -> joint-limit + plane/capsule pyramidal contact rows (+ capsule/capsule rows) ->
+//   primal Newton solve to the exact active-set fixed point (opt.tolerance = 0,
+//   mujoco/build.py:35) -> Euler (implicit joint damping) or RK4 -> env reward (mujoco/envs/*.py).
+//
+// MI355X-specific organisation (why this file exists next to the algorithm description above):
+//   * the path is fp64-VALU bound and one lane owns one rollout, so the limiter is the per-lane
+//     live state: 512 registers (256 VGPR + 256 AGPR at one wave per SIMD) = 256 doubles.
+//     Everything that is touched rarely, or that needs a lane-dependent index, lives in a per-lane
+//     LDS column instead (lane-interleaved, element i of lane t at word i*BLOCK + t: conflict
+//     free for any per-lane index):  q, v, ctrl;  active joint-limit rows (D, aref);  and the
+//     ACTIVE contact rows compacted into K slots of 5 doubles (point, D, aref_n, aref_t) -- a
+//     capsule end that is not within its margin costs no storage at all;
+//   * one fused top-down sweep per dynamics evaluation does kinematics, body velocities, the
+//     Newton-Euler forward recursion, contact detection and limit detection body by body, so
+//     poses and velocities die as soon as the subtree below them is done;
+//   * the constraint Jacobian is never formed.  A contact row is a 3-vector `w` acting on the
+//     spatial velocity of its body:  J x  is one tree pass,  J^T f  one backward pass, and the
+//     Newton Hessian  M + J^T D J  is the composite-rigid-body algorithm run on inertias
+//     augmented by  sum D w w^T ; the tree-sparse L^T D L factorisation has its sparsity
+//     resolved at compile time.
+//
+// The scalar type T is `double` on the device; tests instantiate it on the host with `double`
+// (comparison with the 3-D oracle) and with a counting type (algorithmic flop count for bench.py).
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#include "models_gen.hpp"
+
+#if defined(__HIPCC__)
+#define MBRL_HD __host__ __device__ __forceinline__
+#else
+#define MBRL_HD inline
+#endif
+#define MBRL_UNROLL _Pragma("unroll")
+
+namespace mbrl {
+
+constexpr double kMinVal = 1e-15;
+constexpr unsigned ST_NONFINITE = 1u, ST_NOCONVERGE = 2u, ST_OVERFLOW = 4u, ST_DEGENERATE = 8u;
+constexpr int kMaxNewton = 100;
+constexpr int kMaxLineSearch = 40;
+
+// ---- scalar helpers (overloaded by the host-side counting type) ----
+MBRL_HD double t_abs(double x) { return fabs(x); }
+MBRL_HD double t_max(double x, double y) { return fmax(x, y); }
+MBRL_HD double t_min(double x, double y) { return fmin(x, y); }
+MBRL_HD double t_sqrt(double x) { return sqrt(x); }
+MBRL_HD double t_pow(double x, double y) { return pow(x, y); }
+MBRL_HD double t_fmod(double x, double y) { return fmod(x, y); }
+MBRL_HD double t_cos(double x) { return cos(x); }
+MBRL_HD void t_sincos(double x, double *s, double *c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincos(x, s, c);
+#else
+    *s = sin(x); *c = cos(x);
+#endif
+}
+MBRL_HD bool t_finite(double x) { return x - x == 0.0; }
+MBRL_HD double t_val(double x) { return x; }
+
+template <class T>
+struct Sp {  // planar spatial vector: angular part w, linear part (a, b)
+    T w, a, b;
+};
+
+// per-lane memory column: element i of this lane at p[i * STRIDE]
+template <class T, int STRIDE>
+struct LaneMem {
+    T *p;
+    MBRL_HD T ld(int i) const { return p[i * STRIDE]; }
+    MBRL_HD void st(int i, T x) const { p[i * STRIDE] = x; }
+};
+
+template <class M>
+struct Topo {
+    static constexpr bool body_anc(int anc, int b) {
+        while (b >= 0) {
+            if (b == anc) return true;
+            b = M::parent[b];
+        }
+        return false;
+    }
+    // dof j moves the body of dof i (j <= i in index order)?
+    static constexpr bool dof_anc(int j, int i) { return j <= i && body_anc(M::dof_body[j], M::dof_body[i]); }
+    static constexpr int nlim() { int n = 0; for (int j = 0; j < M::NV; j++) n += M::limited[j] ? 1 : 0; return n; }
+    static constexpr int lim_rank(int j) { int n = 0; for (int i = 0; i < j; i++) n += M::limited[i] ? 1 : 0; return n; }
+    static constexpr int ncand() {
+        if (!M::HAS_FLOOR) return 0;
+        int n = 0; for (int g = 0; g < M::NGEOM; g++) n += M::c_on[g] ? 2 : 0; return n;
+    }
+    static constexpr int cand_rank(int g, int e) {  // index of candidate (g, e) among the floor candidates
+        int n = 0; for (int i = 0; i < g; i++) n += M::c_on[i] ? 2 : 0; return n + e;
+    }
+    static constexpr bool any_child(int b) { for (int i = 0; i < M::NB; i++) if (M::parent[i] == b) return true; return false; }
+    // is b the highest-index child of its parent (the first one a leaf-to-root pass folds)?
+    static constexpr bool first_folded(int b) {
+        for (int o = b + 1; o < M::NB; o++) if (M::parent[o] == M::parent[b]) return false;
+        return true;
+    }
+};
+
+// layout of the per-lane memory column
+template <class M>
+struct Layout {
+    using TP = Topo<M>;
+    static constexpr int NV = M::NV, NU = M::NU;
+    static constexpr int NLIM = TP::nlim(), NCAND = TP::ncand();
+    static constexpr int K = NCAND < 8 ? NCAND : 8;            // contact slots (active rows beyond K: ST_OVERFLOW)
+    static constexpr int OQ = 0, OV = NV, OC = 2 * NV, OL = 2 * NV + NU, OP = OL + 2 * NLIM;
+    static constexpr int OS = OP + 5 * M::NPAIR, NMEM = OS + 5 * K;
+};
+
+template <class M, class T, class Mem>
+struct Lean {
+    static constexpr int NB = M::NB, NV = M::NV, NU = M::NU;
+    using TP = Topo<M>;
+    using LY = Layout<M>;
+    static constexpr int K = LY::K;
+    static_assert(3 * K <= 32 && NV + M::NPAIR <= 32 && LY::NCAND <= 32, "row masks are 32-bit");
+
+    Mem mem;
+    // ---- position-dependent, alive through a dynamics evaluation ----
+    T ra[NV], rb[NV];                    // hinge lever r = O - anchor (O = origin of the root body)
+    T ha[NB], hb[NB], IO[NB];            // first moment m*(com - O) and inertia about O
+    T fsm[NV], qacc[NV], fcon[NV];
+    T site_a, site_b;
+    uint32_t lim_on, lim_hi;             // bit j: limit row of dof j active / it is the upper limit
+    uint32_t con_on;                     // bit = floor candidate (capsule end) that owns a slot
+    uint32_t pair_on;
+    unsigned status;
+    int newton_iters;
+
+    // ------------------------------------------------------------------ motion subspace
+    MBRL_HD Sp<T> Scol(int j) const {
+        Sp<T> r;
+        if (M::dof_type[j] == 0) { r.w = T(0.0); r.a = T(1.0); r.b = T(0.0); }
+        else if (M::dof_type[j] == 1) { r.w = T(0.0); r.a = T(0.0); r.b = T(1.0); }
+        else { r.w = T(M::dof_sgn[j]); r.a = -M::dof_sgn[j] * rb[j]; r.b = M::dof_sgn[j] * ra[j]; }
+        return r;
+    }
+
+    // spatial velocity of every body for generalized velocity x
+    MBRL_HD void vel_pass(const T *x, Sp<T> *V) const {
+        MBRL_UNROLL
+        for (int b = 0; b < NB; b++) {
+            Sp<T> u;
+            if (M::parent[b] >= 0) u = V[M::parent[b]];
+            else { u.w = T(0.0); u.a = T(0.0); u.b = T(0.0); }
+            MBRL_UNROLL
+            for (int k = 0; k < M::dofnum[b]; k++) {
+                const int j = M::dofadr[b] + k;
+                if (M::dof_type[j] == 0) u.a = u.a + x[j];
+                else if (M::dof_type[j] == 1) u.b = u.b + x[j];
+                else {
+                    const T xs = M::dof_sgn[j] * x[j];
+                    u.w = u.w + xs;
+                    u.a = u.a - rb[j] * xs;
+                    u.b = u.b + ra[j] * xs;
+                }
+            }
+            V[b] = u;
+        }
+    }
+
+    // generalized forces from per-body spatial forces (F is destroyed: subtree sums)
+    MBRL_HD void back_pass(Sp<T> *F, T *g) const {
+        MBRL_UNROLL
+        for (int b = NB - 1; b >= 0; b--) {
+            MBRL_UNROLL
+            for (int k = 0; k < M::dofnum[b]; k++) {
+                const int j = M::dofadr[b] + k;
+                if (M::dof_type[j] == 0) g[j] = F[b].a;
+                else if (M::dof_type[j] == 1) g[j] = F[b].b;
+                else g[j] = M::dof_sgn[j] * (F[b].w - rb[j] * F[b].a + ra[j] * F[b].b);
+            }
+            if (M::parent[b] >= 0) {
+                const int p = M::parent[b];
+                F[p].w = F[p].w + F[b].w; F[p].a = F[p].a + F[b].a; F[p].b = F[p].b + F[b].b;
+            }
+        }
+    }
+
+    // rigid-body momentum  I_b * V  (about O)
+    MBRL_HD Sp<T> inert_mul(int b, const Sp<T> &V) const {
+        Sp<T> r;
+        r.w = IO[b] * V.w + (ha[b] * V.b - hb[b] * V.a);
+        r.a = M::mass[b] * V.a - V.w * hb[b];
+        r.b = M::mass[b] * V.b + V.w * ha[b];
+        return r;
+    }
+
+    // ------------------------------------------------------------------ impedance / regulariser
+    // returns D = 1 / R,  R = max(minval, (1 - imp) * RK / imp), and the impedance itself
+    MBRL_HD static T impedance(double dmin, double dmax, double width, double mid, double power, T pm) {
+        if (dmin == dmax || width <= kMinVal) return T(0.5 * (dmin + dmax));
+        const T x = t_abs(pm) / width;
+        T y;
+        if (power == 2.0 && mid == 0.5) {
+            const T u = T(1.0) - x;
+            y = (t_val(x) <= 0.5) ? T(2.0) * x * x : T(1.0) - T(2.0) * u * u;
+        } else if (power == 1.0) {
+            y = x;
+        } else {
+            y = (t_val(x) <= mid) ? t_pow(x, T(power)) / pow(mid, power - 1.0)
+                                  : T(1.0) - t_pow(T(1.0) - x, T(power)) / pow(1.0 - mid, power - 1.0);
+        }
+        T imp = T(dmin) + y * (dmax - dmin);
+        if (t_val(x) >= 1.0) imp = T(dmax);
+        if (t_val(x) <= 0.0) imp = T(dmin);
+        return imp;
+    }
+
+    // ------------------------------------------------------------------ fused top-down sweep
+    // kinematics + body velocities + Newton-Euler forward recursion + constraint detection.
+    // Leaves: ra, rb, ha, hb, IO, site, constraint rows in `mem`, and the per-body net forces F.
+    MBRL_HD void sweep(Sp<T> *F) {
+        lim_on = 0; lim_hi = 0; con_on = 0; pair_on = 0;
+        int nslot = 0;
+        T pa[NB], pb[NB], c[NB], s[NB];
+        Sp<T> V[NB], A[NB];
+        T Ob = T(0.0), Oa = T(0.0);
+        MBRL_UNROLL
+        for (int b = 0; b < NB; b++) {
+            // ---- pose ----
+            T px, py, cc, ss;
+            if (M::parent[b] < 0) {
+                px = T(M::bpos[b][0]); py = T(M::bpos[b][1]); cc = T(1.0); ss = T(0.0);
+            } else {
+                const int p = M::parent[b];
+                px = pa[p] + (c[p] * M::bpos[b][0] - s[p] * M::bpos[b][1]);
+                py = pb[p] + (s[p] * M::bpos[b][0] + c[p] * M::bpos[b][1]);
+                cc = c[p]; ss = s[p];
+            }
+            T qj[3], vj[3], anca[3], ancb[3];
+            MBRL_UNROLL
+            for (int k = 0; k < M::dofnum[b]; k++) {
+                const int j = M::dofadr[b] + k;
+                qj[k] = mem.ld(LY::OQ + j); vj[k] = mem.ld(LY::OV + j);
+                const T dq = qj[k] - M::qpos0[j];
+                if (M::dof_type[j] == 0) px = px + dq;
+                else if (M::dof_type[j] == 1) py = py + dq;
+                else {
+                    const T ax = px + (cc * M::jpos[j][0] - ss * M::jpos[j][1]);
+                    const T ay = py + (ss * M::jpos[j][0] + cc * M::jpos[j][1]);
+                    T sj, cj;
+                    t_sincos(M::dof_sgn[j] * dq, &sj, &cj);
+                    const T cn = cc * cj - ss * sj, sn = ss * cj + cc * sj;
+                    cc = cn; ss = sn;
+                    px = ax - (cc * M::jpos[j][0] - ss * M::jpos[j][1]);
+                    py = ay - (ss * M::jpos[j][0] + cc * M::jpos[j][1]);
+                    anca[k] = ax; ancb[k] = ay;
+                }
+            }
+            if (M::parent[b] < 0) {  // root: its final origin is O; everything else is relative to it
+                Oa = px; Ob = py;
+                MBRL_UNROLL
+                for (int k = 0; k < M::dofnum[b]; k++) {
+                    const int j = M::dofadr[b] + k;
+                    if (M::dof_type[j] == 2) { ra[j] = px - anca[k]; rb[j] = py - ancb[k]; }
+                }
+                pa[b] = T(0.0); pb[b] = T(0.0);
+            } else {
+                MBRL_UNROLL
+                for (int k = 0; k < M::dofnum[b]; k++) {
+                    const int j = M::dofadr[b] + k;
+                    if (M::dof_type[j] == 2) { ra[j] = -anca[k]; rb[j] = -ancb[k]; }
+                }
+                pa[b] = px; pb[b] = py;
+            }
+            c[b] = cc; s[b] = ss;
+            const T cwa = pa[b] + (cc * M::com[b][0] - ss * M::com[b][1]);
+            const T cwb = pb[b] + (ss * M::com[b][0] + cc * M::com[b][1]);
+            ha[b] = M::mass[b] * cwa; hb[b] = M::mass[b] * cwb;
+            IO[b] = M::izz[b] + M::mass[b] * (cwa * cwa + cwb * cwb);
+            if (M::HAS_SITE && b == M::site_body) {
+                site_a = Oa + pa[b] + (cc * M::site_pos[0] - ss * M::site_pos[1]);
+                site_b = Ob + pb[b] + (ss * M::site_pos[0] + cc * M::site_pos[1]);
+            }
+            // ---- velocity and bias acceleration (Newton-Euler forward recursion) ----
+            Sp<T> u, a;
+            if (M::parent[b] >= 0) { u = V[M::parent[b]]; a = A[M::parent[b]]; }
+            else {
+                u.w = T(0.0); u.a = T(0.0); u.b = T(0.0);
+                a.w = T(0.0); a.a = T(-M::GRAV_A); a.b = T(-M::GRAV_B);
+            }
+            MBRL_UNROLL
+            for (int k = 0; k < M::dofnum[b]; k++) {
+                const int j = M::dofadr[b] + k;
+                if (M::dof_type[j] == 2) {
+                    const Sp<T> S = Scol(j);
+                    // Sdot = crm(u) S = (0, -u.w*S.b + u.b*S.w, u.w*S.a - u.a*S.w)
+                    a.a = a.a + (u.b * S.w - u.w * S.b) * vj[k];
+                    a.b = a.b + (u.w * S.a - u.a * S.w) * vj[k];
+                    u.w = u.w + S.w * vj[k]; u.a = u.a + S.a * vj[k]; u.b = u.b + S.b * vj[k];
+                } else if (M::dof_type[j] == 0) {
+                    a.b = a.b + u.w * vj[k];
+                    u.a = u.a + vj[k];
+                } else {
+                    a.a = a.a - u.w * vj[k];
+                    u.b = u.b + vj[k];
+                }
+            }
+            V[b] = u; A[b] = a;
+            {
+                const Sp<T> Ia = inert_mul(b, a), Iv = inert_mul(b, u);
+                // crf(u) Iv = (u.a*Iv.b - u.b*Iv.a, -u.w*Iv.b, u.w*Iv.a)
+                F[b].w = Ia.w + (u.a * Iv.b - u.b * Iv.a);
+                F[b].a = Ia.a - u.w * Iv.b;
+                F[b].b = Ia.b + u.w * Iv.a;
+            }
+            if (M::FLUID) {
+                // inertia-box fluid model: velocity at the body com in body axes
+                const T rca = cwa, rcb = cwb;                                   // com - O
+                const T vca = u.a - u.w * rcb, vcb = u.b + u.w * rca;
+                const T la = cc * vca + ss * vcb, lb = -ss * vca + cc * vcb;
+                const T fla = -M::fl_kv_lin[b] * la - M::fl_kq_a[b] * t_abs(la) * la;
+                const T flb = -M::fl_kv_lin[b] * lb - M::fl_kq_b[b] * t_abs(lb) * lb;
+                const T tq = -M::fl_kv_ang[b] * u.w - M::fl_kq_ang[b] * t_abs(u.w) * u.w;
+                const T fa = cc * fla - ss * flb, fb = ss * fla + cc * flb;
+                F[b].w = F[b].w - (tq + (rca * fb - rcb * fa));
+                F[b].a = F[b].a - fa;
+                F[b].b = F[b].b - fb;
+            }
+            // ---- joint limits of this body's dofs ----
+            MBRL_UNROLL
+            for (int k = 0; k < M::dofnum[b]; k++) {
+                const int j = M::dofadr[b] + k;
+                if (!M::limited[j]) continue;
+                const T dlo = qj[k] - M::range[j][0], dhi = M::range[j][1] - qj[k];
+                const bool lo = t_val(dlo) < M::lim_margin[j], hi = t_val(dhi) < M::lim_margin[j];
+                if (lo || hi) {
+                    const T dist = lo ? dlo : dhi;
+                    const T sg = lo ? T(1.0) : T(-1.0);
+                    const double *si = M::lim_solimp[j];
+                    const T imp = impedance(si[0], si[1], si[2], si[3], si[4], dist - M::lim_margin[j]);
+                    const T R = t_max(T(kMinVal), (T(1.0) - imp) * M::dof_invweight0[j] / imp);
+                    const int li = TP::lim_rank(j);
+                    mem.st(LY::OL + 2 * li, T(1.0) / R);
+                    mem.st(LY::OL + 2 * li + 1,
+                           -M::lim_B[j] * (sg * vj[k]) - M::lim_K[j] * imp * (dist - M::lim_margin[j]));
+                    lim_on |= (1u << j);
+                    if (!lo) lim_hi |= (1u << j);
+                }
+            }
+            // ---- capsule-end / floor contacts of this body's geoms ----
+            if (M::HAS_FLOOR) {
+                MBRL_UNROLL
+                for (int g = 0; g < M::NGEOM; g++) {
+                    if (M::g_body[g] != b || !M::c_on[g]) continue;
+                    MBRL_UNROLL
+                    for (int e = 0; e < 2; e++) {
+                        const double la = e ? M::g_eb[g][0] : M::g_ea[g][0], lb = e ? M::g_eb[g][1] : M::g_ea[g][1];
+                        const T ea = pa[b] + (cc * la - ss * lb);   // sphere centre rel. O
+                        const T eb = pb[b] + (ss * la + cc * lb);
+                        const T dist = ((Ob + eb) - M::FLOOR_Z) - M::g_rad[g];
+                        if (t_val(dist) < M::c_margin[g]) {
+                            if (nslot >= K) { status |= ST_OVERFLOW; continue; }
+                            const T Pa = ea, Pb = eb - (M::g_rad[g] + T(0.5) * dist);
+                            const T pm = dist - M::c_margin[g];
+                            const double *si = M::c_solimp[g];
+                            const T imp = impedance(si[0], si[1], si[2], si[3], si[4], pm);
+                            const T R = t_max(T(kMinVal), (T(1.0) - imp) * M::c_RK[g] / imp);
+                            const T vn = u.b + u.w * Pa, vt = u.a - u.w * Pb;
+                            const int o = LY::OS + 5 * nslot;
+                            mem.st(o, Pa); mem.st(o + 1, Pb); mem.st(o + 2, T(1.0) / R);
+                            mem.st(o + 3, -M::c_B[g] * vn - M::c_K[g] * imp * pm);
+                            mem.st(o + 4, -M::c_B[g] * vt);
+                            con_on |= (1u << TP::cand_rank(g, e));
+                            nslot++;
+                        }
+                    }
+                }
+            }
+        }
+        // ---- capsule-capsule pairs (closest points of the two axis segments, then sphere-sphere) ----
+        MBRL_UNROLL
+        for (int k = 0; k < M::NPAIR; k++) {
+            const int g1 = M::pair_g1[k], g2 = M::pair_g2[k], b1 = M::g_body[g1], b2 = M::g_body[g2];
+            const T p1a = pa[b1] + (c[b1] * M::g_ea[g1][0] - s[b1] * M::g_ea[g1][1]);
+            const T p1b = pb[b1] + (s[b1] * M::g_ea[g1][0] + c[b1] * M::g_ea[g1][1]);
+            const T q1a = pa[b1] + (c[b1] * M::g_eb[g1][0] - s[b1] * M::g_eb[g1][1]);
+            const T q1b = pb[b1] + (s[b1] * M::g_eb[g1][0] + c[b1] * M::g_eb[g1][1]);
+            const T p2a = pa[b2] + (c[b2] * M::g_ea[g2][0] - s[b2] * M::g_ea[g2][1]);
+            const T p2b = pb[b2] + (s[b2] * M::g_ea[g2][0] + c[b2] * M::g_ea[g2][1]);
+            const T q2a = pa[b2] + (c[b2] * M::g_eb[g2][0] - s[b2] * M::g_eb[g2][1]);
+            const T q2b = pb[b2] + (s[b2] * M::g_eb[g2][0] + c[b2] * M::g_eb[g2][1]);
+            const T d1a = q1a - p1a, d1b = q1b - p1b, d2a = q2a - p2a, d2b = q2b - p2b;
+            const T rra = p1a - p2a, rrb = p1b - p2b;
+            const T aa = d1a * d1a + d1b * d1b, ee = d2a * d2a + d2b * d2b, ff = d2a * rra + d2b * rrb;
+            const T cc = d1a * rra + d1b * rrb, bb = d1a * d2a + d1b * d2b;
+            const T den = aa * ee - bb * bb;
+            T ss = (t_val(den) < 1e-12 * t_val(aa) * t_val(ee)) ? T(0.0) : (bb * ff - cc * ee) / den;
+            ss = t_min(T(1.0), t_max(T(0.0), ss));
+            T tt = (bb * ss + ff) / ee;
+            if (t_val(tt) < 0.0) { tt = T(0.0); ss = t_min(T(1.0), t_max(T(0.0), -cc / aa)); }
+            else if (t_val(tt) > 1.0) { tt = T(1.0); ss = t_min(T(1.0), t_max(T(0.0), (bb - cc) / aa)); }
+            const T c1a = p1a + ss * d1a, c1b = p1b + ss * d1b, c2a = p2a + tt * d2a, c2b = p2b + tt * d2b;
+            const T dfa = c2a - c1a, dfb = c2b - c1b;
+            const T len = t_sqrt(dfa * dfa + dfb * dfb);
+            const T dist = len - M::g_rad[g1] - M::g_rad[g2];
+            if (t_val(dist) < M::pair_margin[k]) {
+                if (t_val(len) < 1e-10) status |= ST_DEGENERATE;  // crossing axes: normal is round-off noise
+                T na = T(1.0), nb = T(0.0);
+                if (!(t_val(len) < kMinVal)) { na = dfa / len; nb = dfb / len; }
+                const T Pa = c1a + na * (M::g_rad[g1] + T(0.5) * dist);
+                const T Pb = c1b + nb * (M::g_rad[g1] + T(0.5) * dist);
+                const T pm = dist - M::pair_margin[k];
+                const double *si = M::pair_solimp[k];
+                const T imp = impedance(si[0], si[1], si[2], si[3], si[4], pm);
+                const T R = t_max(T(kMinVal), (T(1.0) - imp) * M::pair_RK[k] / imp);
+                const T w0 = nb * Pa - na * Pb;
+                const T vel = w0 * (V[b2].w - V[b1].w) + na * (V[b2].a - V[b1].a) + nb * (V[b2].b - V[b1].b);
+                const int o = LY::OP + 5 * k;
+                mem.st(o, w0); mem.st(o + 1, na); mem.st(o + 2, nb); mem.st(o + 3, T(1.0) / R);
+                mem.st(o + 4, -M::pair_B[k] * vel - M::pair_K[k] * imp * pm);
+                pair_on |= (1u << k);
+            }
+        }
+    }
+
+    // qfrc_smooth = passive - bias + actuation
+    MBRL_HD void smooth_forces(Sp<T> *F) {
+        T bias[NV];
+        back_pass(F, bias);
+        MBRL_UNROLL
+        for (int j = 0; j < NV; j++) {
+            T f = -bias[j];
+            if (M::stiff[j] != 0.0) f = f - M::stiff[j] * mem.ld(LY::OQ + j);
+            if (M::damp[j] != 0.0) f = f - M::damp[j] * mem.ld(LY::OV + j);
+            fsm[j] = f;
+        }
+        MBRL_UNROLL
+        for (int u = 0; u < NU; u++) {
+            T cu = mem.ld(LY::OC + u);
+            if (M::ctrllimited[u]) cu = t_min(T(M::ctrlrange[u][1]), t_max(T(M::ctrlrange[u][0]), cu));
+            fsm[M::act_dof[u]] = fsm[M::act_dof[u]] + M::gear[u] * cu;
+        }
+    }
+
+    // ------------------------------------------------------------------ CRBA on 3x3 symmetric inertias
+    struct Sym3 { T ww, wa, wb, aa, ab, bb; };
+
+    // H (lower triangle, tree-sparse) = sum_b A_b^T (I_b + aug_b) A_b + diag(add).  Bodies are folded
+    // leaf-to-root and a body's rows are emitted as soon as its subtree is complete, so at most one
+    // composite per tree level is alive.  aug may be null (plain mass matrix).
+    MBRL_HD void crba(const Sym3 *aug, T (*H)[NV], const T *diag_add) const {
+        Sym3 Ic[NB];
+        MBRL_UNROLL
+        for (int b = NB - 1; b >= 0; b--) {
+            Sym3 I;
+            I.ww = IO[b]; I.wa = -hb[b]; I.wb = ha[b]; I.aa = T(M::mass[b]); I.ab = T(0.0); I.bb = T(M::mass[b]);
+            if (aug) {
+                I.ww = I.ww + aug[b].ww; I.wa = I.wa + aug[b].wa; I.wb = I.wb + aug[b].wb;
+                I.aa = I.aa + aug[b].aa; I.ab = I.ab + aug[b].ab; I.bb = I.bb + aug[b].bb;
+            }
+            if (TP::any_child(b)) {   // children were folded into Ic[b] already
+                I.ww = I.ww + Ic[b].ww; I.wa = I.wa + Ic[b].wa; I.wb = I.wb + Ic[b].wb;
+                I.aa = I.aa + Ic[b].aa; I.ab = I.ab + Ic[b].ab; I.bb = I.bb + Ic[b].bb;
+            }
+            MBRL_UNROLL
+            for (int k = M::dofnum[b] - 1; k >= 0; k--) {
+                const int i = M::dofadr[b] + k;
+                const Sp<T> S = Scol(i);
+                Sp<T> Fi;
+                if (M::dof_type[i] == 0) { Fi.w = I.wa; Fi.a = I.aa; Fi.b = I.ab; }
+                else if (M::dof_type[i] == 1) { Fi.w = I.wb; Fi.a = I.ab; Fi.b = I.bb; }
+                else {
+                    Fi.w = I.ww * S.w + I.wa * S.a + I.wb * S.b;
+                    Fi.a = I.wa * S.w + I.aa * S.a + I.ab * S.b;
+                    Fi.b = I.wb * S.w + I.ab * S.a + I.bb * S.b;
+                }
+                MBRL_UNROLL
+                for (int j = 0; j <= i; j++) {
+                    if (!TP::dof_anc(j, i)) continue;
+                    T h;
+                    if (M::dof_type[j] == 0) h = Fi.a;
+                    else if (M::dof_type[j] == 1) h = Fi.b;
+                    else { const Sp<T> Sj = Scol(j); h = Sj.w * Fi.w + Sj.a * Fi.a + Sj.b * Fi.b; }
+                    if (j == i) h = h + diag_add[i];
+                    H[i][j] = h;
+                }
+            }
+            if (M::parent[b] >= 0) {
+                const int p = M::parent[b];
+                if (TP::first_folded(b)) Ic[p] = I;
+                else {
+                    Ic[p].ww = Ic[p].ww + I.ww; Ic[p].wa = Ic[p].wa + I.wa; Ic[p].wb = Ic[p].wb + I.wb;
+                    Ic[p].aa = Ic[p].aa + I.aa; Ic[p].ab = Ic[p].ab + I.ab; Ic[p].bb = Ic[p].bb + I.bb;
+                }
+            }
+        }
+    }
+
+    // in-place tree-sparse L^T D L factorisation; returns false if a pivot is not positive
+    MBRL_HD bool factor(T (*H)[NV]) const {
+        bool ok = true;
+        MBRL_UNROLL
+        for (int k = NV - 1; k >= 0; k--) {
+            if (!(t_val(H[k][k]) > 0.0)) ok = false;
+            const T inv = T(1.0) / H[k][k];
+            MBRL_UNROLL
+            for (int i = k - 1; i >= 0; i--) {
+                if (!TP::dof_anc(i, k)) continue;
+                const T a = H[k][i] * inv;
+                MBRL_UNROLL
+                for (int j = i; j >= 0; j--) {
+                    if (!TP::dof_anc(j, i)) continue;
+                    H[i][j] = H[i][j] - a * H[k][j];
+                }
+                H[k][i] = a;
+            }
+            H[k][k] = inv;  // store 1/D
+        }
+        return ok;
+    }
+
+    MBRL_HD void solve(const T (*H)[NV], T *x) const {
+        MBRL_UNROLL
+        for (int i = NV - 1; i >= 0; i--) {
+            MBRL_UNROLL
+            for (int j = i - 1; j >= 0; j--)
+                if (TP::dof_anc(j, i)) x[j] = x[j] - H[i][j] * x[i];
+        }
+        MBRL_UNROLL
+        for (int i = 0; i < NV; i++) x[i] = x[i] * H[i][i];
+        MBRL_UNROLL
+        for (int i = 0; i < NV; i++) {
+            MBRL_UNROLL
+            for (int j = i - 1; j >= 0; j--)
+                if (TP::dof_anc(j, i)) x[i] = x[i] - H[i][j] * x[j];
+        }
+    }
+
+    // ------------------------------------------------------------------ constraint rows
+    // Row bookkeeping: `lm` bit j = limit row of dof j, bit NV+k = pair row k; `cm` bit 3*slot+r =
+    // row r of the contact in that slot (pyramid: n + mu t, n - mu t, n (weight 2); condim 1: r = 2).
+    MBRL_HD int slot_of(int cand_bit) const { return __builtin_popcount(con_on & ((1u << cand_bit) - 1u)); }
+
+    // residuals at x = qacc: active masks, constraint forces per body, Hessian augmentation, limit terms
+    MBRL_HD void grad_pass(const Sp<T> *Va, const T *x, Sp<T> *Fc, Sym3 *aug, T *flim, T *hdiag,
+                           uint32_t &lm, uint32_t &cm) const {
+        lm = 0; cm = 0;
+        MBRL_UNROLL
+        for (int j = 0; j < NV; j++) {
+            if (!M::limited[j]) continue;
+            if (lim_on & (1u << j)) {
+                const int li = TP::lim_rank(j);
+                const T D = mem.ld(LY::OL + 2 * li), aref = mem.ld(LY::OL + 2 * li + 1);
+                const bool up = (lim_hi >> j) & 1u;
+                const T jar = (up ? -x[j] : x[j]) - aref;
+                if (t_val(jar) < 0.0) {
+                    lm |= 1u << j;
+                    const T f = -D * jar;
+                    flim[j] = up ? -f : f;
+                    hdiag[j] = hdiag[j] + D;
+                }
+            }
+        }
+        MBRL_UNROLL
+        for (int k = 0; k < M::NPAIR; k++) {
+            if (pair_on & (1u << k)) {
+                const int b1 = M::g_body[M::pair_g1[k]], b2 = M::g_body[M::pair_g2[k]];
+                const int o = LY::OP + 5 * k;
+                const T w0 = mem.ld(o), w1 = mem.ld(o + 1), w2 = mem.ld(o + 2), D = mem.ld(o + 3), aref = mem.ld(o + 4);
+                const T jar = (w0 * (Va[b2].w - Va[b1].w) + w1 * (Va[b2].a - Va[b1].a) + w2 * (Va[b2].b - Va[b1].b)) - aref;
+                if (t_val(jar) < 0.0) {
+                    lm |= 1u << (NV + k);
+                    const T f = -D * jar;
+                    Fc[b2].w = Fc[b2].w + f * w0; Fc[b2].a = Fc[b2].a + f * w1; Fc[b2].b = Fc[b2].b + f * w2;
+                    Fc[b1].w = Fc[b1].w - f * w0; Fc[b1].a = Fc[b1].a - f * w1; Fc[b1].b = Fc[b1].b - f * w2;
+                }
+            }
+        }
+        if (!M::HAS_FLOOR) return;
+        MBRL_UNROLL
+        for (int g = 0; g < M::NGEOM; g++) {
+            if (!M::c_on[g]) continue;
+            const int b = M::g_body[g];
+            MBRL_UNROLL
+            for (int e = 0; e < 2; e++) {
+                const int cb = TP::cand_rank(g, e);
+                if (con_on & (1u << cb)) {
+                    const int sl = slot_of(cb), o = LY::OS + 5 * sl;
+                    const T Pa = mem.ld(o), Pb = mem.ld(o + 1), D = mem.ld(o + 2);
+                    const T rn = (Va[b].b + Va[b].w * Pa) - mem.ld(o + 3);
+                    const T rt = (Va[b].a - Va[b].w * Pb) - mem.ld(o + 4);
+                    // accumulated row weights: force f on w = wn*(Pa,0,1) + wt*(-Pb,1,0); Hessian D w w^T
+                    T fn = T(0.0), ft = T(0.0), dnn = T(0.0), dnt = T(0.0), dtt = T(0.0);
+                    if (M::c_dim[g] == 1) {
+                        if (t_val(rn) < 0.0) { cm |= 1u << (3 * sl + 2); fn = -D * rn; dnn = D; }
+                    } else {
+                        const double mu = M::c_mu[g];
+                        const T r0 = rn + mu * rt, r1 = rn - mu * rt;
+                        if (t_val(r0) < 0.0) {
+                            cm |= 1u << (3 * sl);
+                            const T f = -D * r0;
+                            fn = fn + f; ft = ft + mu * f; dnn = dnn + D; dnt = dnt + mu * D; dtt = dtt + (mu * mu) * D;
+                        }
+                        if (t_val(r1) < 0.0) {
+                            cm |= 1u << (3 * sl + 1);
+                            const T f = -D * r1;
+                            fn = fn + f; ft = ft - mu * f; dnn = dnn + D; dnt = dnt - mu * D; dtt = dtt + (mu * mu) * D;
+                        }
+                        if (t_val(rn) < 0.0) {
+                            cm |= 1u << (3 * sl + 2);
+                            const T D2 = T(2.0) * D;
+                            fn = fn - D2 * rn; dnn = dnn + D2;
+                        }
+                    }
+                    if (cm & (7u << (3 * sl))) {
+                        // n-direction (Pa, 0, 1), t-direction (-Pb, 1, 0)
+                        Fc[b].w = Fc[b].w + (fn * Pa - ft * Pb); Fc[b].a = Fc[b].a + ft; Fc[b].b = Fc[b].b + fn;
+                        if (aug) {
+                            aug[b].ww = aug[b].ww + ((dnn * Pa) * Pa - T(2.0) * (dnt * Pa) * Pb + (dtt * Pb) * Pb);
+                            aug[b].wa = aug[b].wa + (dnt * Pa - dtt * Pb);
+                            aug[b].wb = aug[b].wb + (dnn * Pa - dnt * Pb);
+                            aug[b].aa = aug[b].aa + dtt; aug[b].ab = aug[b].ab + dnt; aug[b].bb = aug[b].bb + dnn;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // derivative g and curvature h of the constraint cost along the search direction at step alpha
+    MBRL_HD void line_pass(const Sp<T> *Va, const Sp<T> *Vs, const T *x, const T *sx, T alpha, T &g, T &h,
+                           uint32_t &lm, uint32_t &cm) const {
+        lm = 0; cm = 0;
+        MBRL_UNROLL
+        for (int j = 0; j < NV; j++) {
+            if (!M::limited[j]) continue;
+            if (lim_on & (1u << j)) {
+                const int li = TP::lim_rank(j);
+                const T D = mem.ld(LY::OL + 2 * li), aref = mem.ld(LY::OL + 2 * li + 1);
+                const bool up = (lim_hi >> j) & 1u;
+                const T jar = (up ? -x[j] : x[j]) - aref, jv = up ? -sx[j] : sx[j];
+                const T r = jar + alpha * jv;
+                if (t_val(r) < 0.0) { lm |= 1u << j; g = g + D * r * jv; h = h + D * jv * jv; }
+            }
+        }
+        MBRL_UNROLL
+        for (int k = 0; k < M::NPAIR; k++) {
+            if (pair_on & (1u << k)) {
+                const int b1 = M::g_body[M::pair_g1[k]], b2 = M::g_body[M::pair_g2[k]];
+                const int o = LY::OP + 5 * k;
+                const T w0 = mem.ld(o), w1 = mem.ld(o + 1), w2 = mem.ld(o + 2), D = mem.ld(o + 3), aref = mem.ld(o + 4);
+                const T jar = (w0 * (Va[b2].w - Va[b1].w) + w1 * (Va[b2].a - Va[b1].a) + w2 * (Va[b2].b - Va[b1].b)) - aref;
+                const T jv = w0 * (Vs[b2].w - Vs[b1].w) + w1 * (Vs[b2].a - Vs[b1].a) + w2 * (Vs[b2].b - Vs[b1].b);
+                const T r = jar + alpha * jv;
+                if (t_val(r) < 0.0) { lm |= 1u << (NV + k); g = g + D * r * jv; h = h + D * jv * jv; }
+            }
+        }
+        if (!M::HAS_FLOOR) return;
+        MBRL_UNROLL
+        for (int gi = 0; gi < M::NGEOM; gi++) {
+            if (!M::c_on[gi]) continue;
+            const int b = M::g_body[gi];
+            MBRL_UNROLL
+            for (int e = 0; e < 2; e++) {
+                const int cb = TP::cand_rank(gi, e);
+                if (con_on & (1u << cb)) {
+                    const int sl = slot_of(cb), o = LY::OS + 5 * sl;
+                    const T Pa = mem.ld(o), Pb = mem.ld(o + 1), D = mem.ld(o + 2);
+                    const T rn = (Va[b].b + Va[b].w * Pa) - mem.ld(o + 3);
+                    const T rt = (Va[b].a - Va[b].w * Pb) - mem.ld(o + 4);
+                    const T sn = Vs[b].b + Vs[b].w * Pa, st = Vs[b].a - Vs[b].w * Pb;
+                    if (M::c_dim[gi] == 1) {
+                        const T r = rn + alpha * sn;
+                        if (t_val(r) < 0.0) { cm |= 1u << (3 * sl + 2); g = g + D * r * sn; h = h + D * sn * sn; }
+                    } else {
+                        const double mu = M::c_mu[gi];
+                        const T j0 = sn + mu * st, j1 = sn - mu * st;
+                        const T r0 = (rn + mu * rt) + alpha * j0, r1 = (rn - mu * rt) + alpha * j1, r2 = rn + alpha * sn;
+                        if (t_val(r0) < 0.0) { cm |= 1u << (3 * sl); g = g + D * r0 * j0; h = h + D * j0 * j0; }
+                        if (t_val(r1) < 0.0) { cm |= 1u << (3 * sl + 1); g = g + D * r1 * j1; h = h + D * j1 * j1; }
+                        if (t_val(r2) < 0.0) {
+                            cm |= 1u << (3 * sl + 2);
+                            const T D2 = T(2.0) * D;
+                            g = g + D2 * r2 * sn; h = h + D2 * sn * sn;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // explicit D r r^T of an active pair row on the dofs between its two bodies (b1 is an ancestor of b2)
+    MBRL_HD void pair_hessian(uint32_t lm, T (*H)[NV]) const {
+        MBRL_UNROLL
+        for (int k = 0; k < M::NPAIR; k++) {
+            if (lm & (1u << (NV + k))) {
+                const int b1 = M::g_body[M::pair_g1[k]], b2 = M::g_body[M::pair_g2[k]];
+                const int o = LY::OP + 5 * k;
+                const T w0 = mem.ld(o), w1 = mem.ld(o + 1), w2 = mem.ld(o + 2), D = mem.ld(o + 3);
+                T rr[NV];
+                MBRL_UNROLL
+                for (int j = 0; j < NV; j++) {
+                    if (!(TP::body_anc(M::dof_body[j], b2) && !TP::body_anc(M::dof_body[j], b1))) continue;
+                    const Sp<T> Sj = Scol(j);
+                    rr[j] = w0 * Sj.w + w1 * Sj.a + w2 * Sj.b;
+                }
+                MBRL_UNROLL
+                for (int i = 0; i < NV; i++) {
+                    if (!(TP::body_anc(M::dof_body[i], b2) && !TP::body_anc(M::dof_body[i], b1))) continue;
+                    MBRL_UNROLL
+                    for (int j = 0; j <= i; j++) {
+                        if (!(TP::body_anc(M::dof_body[j], b2) && !TP::body_anc(M::dof_body[j], b1))) continue;
+                        H[i][j] = H[i][j] + D * rr[i] * rr[j];
+                    }
+                }
+            }
+        }
+    }
+
+    // primal Newton with exact line search, run until the active set reproduces itself.
+    // In: qacc = unconstrained acceleration.  Out: qacc, fcon.
+    MBRL_HD void solve_constraints() {
+        MBRL_UNROLL
+        for (int j = 0; j < NV; j++) fcon[j] = T(0.0);
+        newton_iters = 0;
+        if (lim_on == 0 && con_on == 0 && pair_on == 0) return;
+        uint32_t plm = ~0u, pcm = ~0u;
+        bool converged = false;
+        for (int it = 0; it <= kMaxNewton; it++) {
+            Sp<T> Va[NB], Fc[NB];
+            Sym3 aug[NB];
+            T flim[NV], hdiag[NV];
+            vel_pass(qacc, Va);
+            MBRL_UNROLL
+            for (int b = 0; b < NB; b++) {
+                Fc[b].w = T(0.0); Fc[b].a = T(0.0); Fc[b].b = T(0.0);
+                aug[b].ww = T(0.0); aug[b].wa = T(0.0); aug[b].wb = T(0.0);
+                aug[b].aa = T(0.0); aug[b].ab = T(0.0); aug[b].bb = T(0.0);
+            }
+            MBRL_UNROLL
+            for (int j = 0; j < NV; j++) { flim[j] = T(0.0); hdiag[j] = T(M::arma[j]); }
+            uint32_t lm, cm;
+            grad_pass(Va, qacc, Fc, aug, flim, hdiag, lm, cm);
+            // constraint force at the current point
+            T jtf[NV];
+            back_pass(Fc, jtf);
+            MBRL_UNROLL
+            for (int j = 0; j < NV; j++) jtf[j] = jtf[j] + flim[j];
+            if ((lm == plm && cm == pcm) || it == kMaxNewton) {
+                converged = (lm == plm && cm == pcm);
+                MBRL_UNROLL
+                for (int j = 0; j < NV; j++) fcon[j] = jtf[j];
+                break;
+            }
+            plm = lm; pcm = cm;
+            newton_iters = it + 1;
+            // gradient  M qacc - qfrc_smooth - J^T f
+            T Ma[NV], sx[NV];
+            {
+                Sp<T> Fm[NB];
+                MBRL_UNROLL
+                for (int b = 0; b < NB; b++) Fm[b] = inert_mul(b, Va[b]);
+                back_pass(Fm, Ma);
+            }
+            T H[NV][NV];
+            crba(aug, H, hdiag);
+            pair_hessian(lm, H);
+            const bool ok = factor(H);
+            if (!ok) { status |= ST_NONFINITE; break; }
+            T a1 = T(0.0);
+            MBRL_UNROLL
+            for (int j = 0; j < NV; j++) {
+                Ma[j] = (Ma[j] + M::arma[j] * qacc[j]) - fsm[j];     // M qacc - qfrc_smooth
+                sx[j] = -(Ma[j] - jtf[j]);
+            }
+            solve(H, sx);
+            T snorm = T(0.0), qnorm = T(0.0);
+            MBRL_UNROLL
+            for (int j = 0; j < NV; j++) { snorm = snorm + sx[j] * sx[j]; qnorm = qnorm + qacc[j] * qacc[j]; a1 = a1 + sx[j] * Ma[j]; }
+            if (!t_finite(snorm)) { status |= ST_NONFINITE; break; }
+            if (t_val(t_sqrt(snorm)) <= 1e-15 * (1.0 + t_val(t_sqrt(qnorm)))) {
+                converged = true;
+                MBRL_UNROLL
+                for (int j = 0; j < NV; j++) fcon[j] = jtf[j];
+                break;
+            }
+            // exact line search: root of the piecewise-linear derivative (safeguarded Newton)
+            Sp<T> Vs[NB];
+            vel_pass(sx, Vs);
+            T a2 = T(0.0);
+            MBRL_UNROLL
+            for (int b = 0; b < NB; b++) {
+                const Sp<T> Is = inert_mul(b, Vs[b]);
+                a2 = a2 + (Vs[b].w * Is.w + Vs[b].a * Is.a + Vs[b].b * Is.b);
+            }
+            MBRL_UNROLL
+            for (int j = 0; j < NV; j++) a2 = a2 + M::arma[j] * sx[j] * sx[j];
+            T alpha = T(1.0), lo = T(0.0), hi = T(-1.0);  // hi < 0: no upper bracket yet
+            uint32_t llm = lm, lcm = cm;                   // active set the current alpha was derived from
+            for (int ls = 0; ls < kMaxLineSearch; ls++) {
+                T g = a1 + alpha * a2, h = a2;
+                uint32_t nlm, ncm;
+                line_pass(Va, Vs, qacc, sx, alpha, g, h, nlm, ncm);
+                if (nlm == llm && ncm == lcm) break;       // alpha is the exact root of its own piece
+                llm = nlm; lcm = ncm;
+                if (t_val(g) < 0.0) lo = alpha; else hi = alpha;
+                T an = alpha - g / h;
+                const bool inside = t_val(an) > t_val(lo) && (t_val(hi) < 0.0 || t_val(an) < t_val(hi));
+                if (!inside) an = (t_val(hi) < 0.0) ? T(2.0) * alpha : T(0.5) * (lo + hi);
+                alpha = an;
+            }
+            MBRL_UNROLL
+            for (int j = 0; j < NV; j++) qacc[j] = qacc[j] + alpha * sx[j];
+        }
+        if (!converged) status |= ST_NOCONVERGE;
+    }
+
+    // ------------------------------------------------------------------ mj_forward
+    MBRL_HD void forward() {
+        {
+            Sp<T> F[NB];
+            sweep(F);
+            smooth_forces(F);
+        }
+        const bool constrained = (lim_on | con_on | pair_on) != 0;
+        if (M::RK4 || !M::ANY_DAMPING || constrained) {   // Euler with implicit damping needs qacc only for the solver
+            T H[NV][NV], arm[NV];
+            MBRL_UNROLL
+            for (int j = 0; j < NV; j++) { arm[j] = T(M::arma[j]); qacc[j] = fsm[j]; }
+            crba(nullptr, H, arm);
+            if (!factor(H)) status |= ST_NONFINITE;
+            solve(H, qacc);
+        }
+        solve_constraints();
+    }
+
+    // ------------------------------------------------------------------ integrators
+    MBRL_HD void euler() {
+        T x[NV];
+        if (M::ANY_DAMPING) {
+            T H[NV][NV], dg[NV];
+            MBRL_UNROLL
+            for (int j = 0; j < NV; j++) { dg[j] = T(M::arma[j]) + T(M::DT) * M::damp[j]; x[j] = fsm[j] + fcon[j]; }
+            crba(nullptr, H, dg);
+            if (!factor(H)) status |= ST_NONFINITE;
+            solve(H, x);
+        } else {
+            MBRL_UNROLL
+            for (int j = 0; j < NV; j++) x[j] = qacc[j];
+        }
+        MBRL_UNROLL
+        for (int j = 0; j < NV; j++) {
+            const T vn = mem.ld(LY::OV + j) + M::DT * x[j];
+            mem.st(LY::OV + j, vn);
+            mem.st(LY::OQ + j, mem.ld(LY::OQ + j) + M::DT * vn);
+        }
+    }
+
+    MBRL_HD void step() {
+        forward();
+        if (!M::RK4) { euler(); return; }
+        // classic RK4; stage i uses only stage i-1 (tableau 1/2, 1/2, 1), weights 1/6 1/3 1/3 1/6
+        T q0[NV], v0[NV], aq[NV], av[NV];
+        MBRL_UNROLL
+        for (int j = 0; j < NV; j++) {
+            q0[j] = mem.ld(LY::OQ + j); v0[j] = mem.ld(LY::OV + j);
+            aq[j] = T(1.0 / 6) * v0[j]; av[j] = T(1.0 / 6) * qacc[j];
+        }
+        for (int i = 1; i < 4; i++) {
+            const double ai = (i == 3) ? 1.0 : 0.5, bi = (i == 3) ? 1.0 / 6 : 1.0 / 3;
+            MBRL_UNROLL
+            for (int j = 0; j < NV; j++) {
+                const T dv = ai * mem.ld(LY::OV + j), da = ai * qacc[j];
+                mem.st(LY::OQ + j, q0[j] + M::DT * dv);
+                mem.st(LY::OV + j, v0[j] + M::DT * da);
+            }
+            forward();
+            MBRL_UNROLL
+            for (int j = 0; j < NV; j++) { aq[j] = aq[j] + bi * mem.ld(LY::OV + j); av[j] = av[j] + bi * qacc[j]; }
+        }
+        MBRL_UNROLL
+        for (int j = 0; j < NV; j++) { mem.st(LY::OQ + j, q0[j] + M::DT * aq[j]); mem.st(LY::OV + j, v0[j] + M::DT * av[j]); }
+    }
+
+    // ------------------------------------------------------------------ env.step
+    // state and ctrl are in `mem`; returns the reward.
+    MBRL_HD T env_step(int frame_skip) {
+        const T xb = mem.ld(LY::OQ);
+        const double dt = M::DT * frame_skip;
+        for (int k = 0; k < frame_skip; k++) step();
+        T asq = T(0.0);
+        MBRL_UNROLL
+        for (int u = 0; u < NU; u++) { const T cu = mem.ld(LY::OC + u); asq = asq + cu * cu; }
+        const double PI = 3.14159265358979323846;
+        const T q0 = mem.ld(LY::OQ);
+        T r = T(0.0);
+        if (M::REWARD == 0) {         // inverted_pendulum.py:26-35
+            const T y = T(0.6) * t_cos(mem.ld(LY::OQ + 1)), x = y;
+            const T cu = mem.ld(LY::OC);
+            r = -(T(0.01) * (x * x) + (y - T(1.0)) * (y - T(1.0))) - T(0.001) * (cu * cu);
+        } else if (M::REWARD == 1) {  // inverted_double_pendulum.py:28-33 (stale site_xpos)
+            const T x = site_a, y = site_b;
+            const T pen = T(0.01) * (x * x) + (y - T(2.0)) * (y - T(2.0));
+            const T v1 = mem.ld(LY::OV + 1), v2 = mem.ld(LY::OV + (NV > 2 ? 2 : 0));
+            const T vp = T(1e-3) * (v1 * v1) + T(5e-3) * (v2 * v2);
+            r = -pen - vp;
+        } else if (M::REWARD == 2) {  // swimmer.py:23-29
+            r = (q0 - xb) / dt + (T(-0.0001) * asq);
+        } else if (M::REWARD == 3) {  // hopper.py:30-41
+            const T q1 = mem.ld(LY::OQ + 1), q2 = mem.ld(LY::OQ + (NV > 2 ? 2 : 0));
+            r = (q0 - xb) / dt;
+            T aa = t_fmod(t_abs(q2), T(2 * PI));
+            if (t_val(aa) > PI) aa = T(2 * PI) - aa;
+            const T c1 = T(1.0) / (T(1.0) + t_pow(T(200.0), -(q1 / 1.25) + T(0.5)));
+            const T c2 = T(1.0) / (T(1.0) + t_pow(T(200.0), -((T(PI) - aa) / PI) + T(0.5)));
+            r = r + (c1 * 1.0 + c2 * 1.0);
+            r = r - T(1e-3) * asq;
+        } else if (M::REWARD == 4) {  // walker2d.py:23-30
+            const T q1 = mem.ld(LY::OQ + 1), q2 = mem.ld(LY::OQ + (NV > 2 ? 2 : 0));
+            r = (q0 - xb) / dt;
+            const T coeff = t_min(t_max(q1 / 0.8, T(0.0)), T(1.0)) * 0.5 +
+                            t_max((T(PI) - t_abs(q2)) / PI, T(1.0)) * 0.5;
+            r = r + coeff * 1.0;
+            r = r - T(1e-3) * asq;
+        } else {                      // half_cheetah.py:25-31
+            r = T(-0.01) * asq + (q0 - xb) / dt;
+        }
+        return r;
+    }
+
+    MBRL_HD void check_finite() {
+        bool ok = true;
+        MBRL_UNROLL
+        for (int j = 0; j < NV; j++) ok = ok && t_finite(mem.ld(LY::OQ + j)) && t_finite(mem.ld(LY::OV + j));
+        if (!ok) status |= ST_NONFINITE;
+    }
+};
+
+}  // namespace mbrl

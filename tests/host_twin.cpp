@@ -1,9 +1,9 @@
-// Host build of the kernel's per-lane simulator (planar_sim.hpp) -- TEST TOOL ONLY.
+// Host build of the kernel's per-lane simulator (planar_lean.hpp) -- TEST TOOL ONLY.
 // Lets CPU tests compare the planar formulation with the 3-D oracle without a GPU and
 // counts its floating-point operations (FMA = 2, add/mul = 1, div/sqrt/transcendental = 1).
 #include <cstdint>
 #include <cstring>
-#include "../model-based-rl_amd/csrc/planar_sim.hpp"
+#include "../model-based-rl_amd/csrc/planar_lean.hpp"
 
 namespace mbrl {
 struct Cnt {
@@ -41,34 +41,42 @@ inline double t_val(Cnt a) { return a.x; }
 using namespace mbrl;
 
 template <class M, class T>
-static void load(Sim<M, T> &S, const double *q, const double *v, const double *c) {
-    for (int j = 0; j < M::NV; j++) { S.q[j] = T(q[j]); S.v[j] = T(v[j]); }
-    for (int u = 0; u < M::NU; u++) S.ctrl[u] = T(c[u]);
-    S.status = 0;
-}
+struct Host {
+    T col[Layout<M>::NMEM > 0 ? Layout<M>::NMEM : 1];
+    Lean<M, T, LaneMem<T, 1>> S;
+    void load(const double *q, const double *v, const double *c) {
+        using LY = Layout<M>;
+        S.mem.p = col;
+        for (int j = 0; j < M::NV; j++) { col[LY::OQ + j] = T(q[j]); col[LY::OV + j] = T(v[j]); }
+        for (int u = 0; u < M::NU; u++) col[LY::OC + u] = T(c[u]);
+        S.status = 0;
+    }
+};
 
 template <class M>
-static int fwd(const double *q, const double *v, const double *c, double *qacc, double *qs, double *fsm,
-               double *fcon, int *iters) {
-    Sim<M, double> S;
-    load(S, q, v, c);
-    S.forward();
-    for (int j = 0; j < M::NV; j++) { qacc[j] = S.qacc[j]; qs[j] = S.qs[j]; fsm[j] = S.fsm[j]; fcon[j] = S.fcon[j]; }
-    *iters = S.newton_iters;
-    return (int)S.status;
+static int fwd(const double *q, const double *v, const double *c, double *qacc, double *fsm, double *fcon,
+               int *iters, int *nactive) {
+    Host<M, double> h;
+    h.load(q, v, c);
+    h.S.forward();
+    for (int j = 0; j < M::NV; j++) { qacc[j] = h.S.qacc[j]; fsm[j] = h.S.fsm[j]; fcon[j] = h.S.fcon[j]; }
+    *iters = h.S.newton_iters;
+    *nactive = __builtin_popcount(h.S.con_on);
+    return (int)h.S.status;
 }
 
 template <class M, class T>
 static void stepN(int frame_skip, int64_t N, const double *q, const double *v, const double *c, double *qn,
                   double *vn, double *r, uint32_t *st) {
+    using LY = Layout<M>;
     for (int64_t i = 0; i < N; i++) {
-        Sim<M, T> S;
-        load(S, q + i * M::NV, v + i * M::NV, c + i * M::NU);
-        T rew = S.env_step(frame_skip > 0 ? frame_skip : M::FRAME_SKIP);
-        S.check_finite();
-        for (int j = 0; j < M::NV; j++) { qn[i * M::NV + j] = t_val(S.q[j]); vn[i * M::NV + j] = t_val(S.v[j]); }
+        Host<M, T> h;
+        h.load(q + i * M::NV, v + i * M::NV, c + i * M::NU);
+        T rew = h.S.env_step(frame_skip > 0 ? frame_skip : M::FRAME_SKIP);
+        h.S.check_finite();
+        for (int j = 0; j < M::NV; j++) { qn[i * M::NV + j] = t_val(h.col[LY::OQ + j]); vn[i * M::NV + j] = t_val(h.col[LY::OV + j]); }
         r[i] = t_val(rew);
-        st[i] = S.status;
+        st[i] = h.S.status;
     }
 }
 
@@ -84,10 +92,11 @@ static void stepN(int frame_skip, int64_t N, const double *q, const double *v, c
     }
 
 extern "C" {
-int twin_forward(int id, const double *q, const double *v, const double *c, double *qacc, double *qs, double *fsm,
-                 double *fcon, int *iters) {
+// one dynamics evaluation (mj_forward); nactive = floor contacts that own a slot
+int twin_forward(int id, const double *q, const double *v, const double *c, double *qacc, double *fsm,
+                 double *fcon, int *iters, int *nactive) {
     int rc = 0;
-    DISPATCH(id, rc = fwd<M>(q, v, c, qacc, qs, fsm, fcon, iters));
+    DISPATCH(id, rc = fwd<M>(q, v, c, qacc, fsm, fcon, iters, nactive));
     return rc;
 }
 int twin_step(int id, int frame_skip, int64_t N, const double *q, const double *v, const double *c, double *qn,
