@@ -33,7 +33,7 @@ def build_hip(force=False, verbose=False):
     compile_planar.write_header()
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed", "-mllvm", "-pragma-unroll-threshold=1000000",
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed", "-mllvm", "-pragma-unroll-threshold=1000000", "-mllvm", "-disable-machine-licm",
            "-o", LIB + ".tmp", os.path.join(CSRC, "mbrl_hip.hip")]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

@@ -40,6 +40,7 @@
 #define MBRL_HD inline
 #endif
 #define MBRL_UNROLL _Pragma("unroll")
+#define MBRL_NOUNROLL _Pragma("nounroll")
 
 namespace mbrl {
 
@@ -56,15 +57,46 @@ MBRL_HD double t_sqrt(double x) { return sqrt(x); }
 MBRL_HD double t_pow(double x, double y) { return pow(x, y); }
 MBRL_HD double t_fmod(double x, double y) { return fmod(x, y); }
 MBRL_HD double t_cos(double x) { return cos(x); }
-MBRL_HD void t_sincos(double x, double *s, double *c) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    sincos(x, s, c);
-#else
-    *s = sin(x); *c = cos(x);
-#endif
-}
 MBRL_HD bool t_finite(double x) { return x - x == 0.0; }
 MBRL_HD double t_val(double x) { return x; }
+MBRL_HD double t_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+MBRL_HD double t_rint(double x) { return __builtin_rint(x); }
+MBRL_HD double t_rcp(double x) {   // reciprocal to ~1 ulp (pivot inverses, regularisers)
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+#else
+    return 1.0 / x;
+#endif
+}
+
+// sin and cos of a joint angle: two-term Cody-Waite reduction by pi/2 and the fdlibm kernel
+// polynomials, branch-free (|x| < ~1e5 keeps the reduction exact to an ulp; joint angles are O(1)).
+template <class T>
+MBRL_HD void t_sincos(T x, T *s, T *c) {
+    const T k = t_rint(x * T(6.36619772367581382433e-01));
+    T r = t_fma(-k, T(1.5707963267948966), x);
+    r = t_fma(-k, T(6.123233995736766e-17), r);
+    const T z = r * r;
+    T ps = t_fma(z, T(1.58969099521155010221e-10), T(-2.50507602534068634195e-08));
+    ps = t_fma(z, ps, T(2.75573137070700676789e-06));
+    ps = t_fma(z, ps, T(-1.98412698298579493134e-04));
+    ps = t_fma(z, ps, T(8.33333333332248946124e-03));
+    ps = t_fma(z, ps, T(-1.66666666666666324348e-01));
+    const T sr = t_fma(r * z, ps, r);
+    T pc = t_fma(z, T(-1.13596475577881948265e-11), T(2.08757232129817482790e-09));
+    pc = t_fma(z, pc, T(-2.75573143513906633035e-07));
+    pc = t_fma(z, pc, T(2.48015872894767294178e-05));
+    pc = t_fma(z, pc, T(-1.38888888888741095749e-03));
+    pc = t_fma(z, pc, T(4.16666666666666019037e-02));
+    const T cr = t_fma(z * z, pc, t_fma(z, T(-0.5), T(1.0)));
+    const int q = int(t_val(k)) & 3;
+    const T ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
+    *s = (q & 2) ? -ss : ss;
+    *c = ((q + 1) & 2) ? -cc : cc;
+}
 
 template <class T>
 struct Sp {  // planar spatial vector: angular part w, linear part (a, b)
@@ -79,8 +111,12 @@ struct LaneMem {
     MBRL_HD void st(int i, T x) const { p[i * STRIDE] = x; }
 };
 
+// Topology predicates of a model, tabulated at compile time.  (They are looked up with unrolled loop
+// variables; a constexpr FUNCTION called that way is ordinary run-time code to the optimiser -- the
+// ancestor walk became scalar loads and loops inside the factorisation -- a constant TABLE folds.)
 template <class M>
 struct Topo {
+    static constexpr int NB = M::NB, NV = M::NV, NG = M::NGEOM, NPR = M::NPAIR > 0 ? M::NPAIR : 1;
     static constexpr bool body_anc(int anc, int b) {
         while (b >= 0) {
             if (b == anc) return true;
@@ -88,23 +124,42 @@ struct Topo {
         }
         return false;
     }
-    // dof j moves the body of dof i (j <= i in index order)?
-    static constexpr bool dof_anc(int j, int i) { return j <= i && body_anc(M::dof_body[j], M::dof_body[i]); }
-    static constexpr int nlim() { int n = 0; for (int j = 0; j < M::NV; j++) n += M::limited[j] ? 1 : 0; return n; }
-    static constexpr int lim_rank(int j) { int n = 0; for (int i = 0; i < j; i++) n += M::limited[i] ? 1 : 0; return n; }
-    static constexpr int ncand() {
-        if (!M::HAS_FLOOR) return 0;
-        int n = 0; for (int g = 0; g < M::NGEOM; g++) n += M::c_on[g] ? 2 : 0; return n;
+    struct Tables {
+        bool dof_anc[NV][NV];     // [j][i]: dof j moves the body of dof i (j <= i in index order)
+        int lim_rank[NV];         // index of dof j among the limited dofs
+        int cand_rank[NG][2];     // index of capsule end (g, e) among the floor-contact candidates
+        bool any_child[NB];
+        bool first_folded[NB];    // b is the highest-index child of its parent (first one a leaf-to-root pass folds)
+        bool between[NPR][NV];    // pair k: dof j moves body 2 but not body 1 of the pair
+        int nlim, ncand;
+    };
+    static constexpr Tables make() {
+        Tables t{};
+        for (int j = 0; j < NV; j++)
+            for (int i = 0; i < NV; i++) t.dof_anc[j][i] = j <= i && body_anc(M::dof_body[j], M::dof_body[i]);
+        int n = 0;
+        for (int j = 0; j < NV; j++) { t.lim_rank[j] = n; n += M::limited[j] ? 1 : 0; }
+        t.nlim = n;
+        n = 0;
+        for (int g = 0; g < NG; g++) {
+            t.cand_rank[g][0] = n; t.cand_rank[g][1] = n + 1;
+            n += (M::HAS_FLOOR && M::c_on[g]) ? 2 : 0;
+        }
+        t.ncand = n;
+        for (int b = 0; b < NB; b++) {
+            t.any_child[b] = false; t.first_folded[b] = true;
+            for (int o = 0; o < NB; o++) {
+                if (M::parent[o] == b) t.any_child[b] = true;
+                if (o > b && M::parent[o] == M::parent[b]) t.first_folded[b] = false;
+            }
+        }
+        for (int k = 0; k < M::NPAIR; k++) {
+            const int b1 = M::g_body[M::pair_g1[k]], b2 = M::g_body[M::pair_g2[k]];
+            for (int j = 0; j < NV; j++) t.between[k][j] = body_anc(M::dof_body[j], b2) && !body_anc(M::dof_body[j], b1);
+        }
+        return t;
     }
-    static constexpr int cand_rank(int g, int e) {  // index of candidate (g, e) among the floor candidates
-        int n = 0; for (int i = 0; i < g; i++) n += M::c_on[i] ? 2 : 0; return n + e;
-    }
-    static constexpr bool any_child(int b) { for (int i = 0; i < M::NB; i++) if (M::parent[i] == b) return true; return false; }
-    // is b the highest-index child of its parent (the first one a leaf-to-root pass folds)?
-    static constexpr bool first_folded(int b) {
-        for (int o = b + 1; o < M::NB; o++) if (M::parent[o] == M::parent[b]) return false;
-        return true;
-    }
+    static constexpr Tables T = make();
 };
 
 // layout of the per-lane memory column
@@ -112,7 +167,7 @@ template <class M>
 struct Layout {
     using TP = Topo<M>;
     static constexpr int NV = M::NV, NU = M::NU;
-    static constexpr int NLIM = TP::nlim(), NCAND = TP::ncand();
+    static constexpr int NLIM = TP::T.nlim, NCAND = TP::T.ncand;
     static constexpr int K = NCAND < 8 ? NCAND : 8;            // contact slots (active rows beyond K: ST_OVERFLOW)
     static constexpr int OQ = 0, OV = NV, OC = 2 * NV, OL = 2 * NV + NU, OP = OL + 2 * NLIM;
     static constexpr int OS = OP + 5 * M::NPAIR, NMEM = OS + 5 * K;
@@ -201,7 +256,7 @@ struct Lean {
     // returns D = 1 / R,  R = max(minval, (1 - imp) * RK / imp), and the impedance itself
     MBRL_HD static T impedance(double dmin, double dmax, double width, double mid, double power, T pm) {
         if (dmin == dmax || width <= kMinVal) return T(0.5 * (dmin + dmax));
-        const T x = t_abs(pm) / width;
+        const T x = t_abs(pm) * (1.0 / width);
         T y;
         if (power == 2.0 && mid == 0.5) {
             const T u = T(1.0) - x;
@@ -339,11 +394,11 @@ struct Lean {
                 if (lo || hi) {
                     const T dist = lo ? dlo : dhi;
                     const T sg = lo ? T(1.0) : T(-1.0);
-                    const double *si = M::lim_solimp[j];
-                    const T imp = impedance(si[0], si[1], si[2], si[3], si[4], dist - M::lim_margin[j]);
+                    const T imp = impedance(M::lim_solimp[j][0], M::lim_solimp[j][1], M::lim_solimp[j][2],
+                                            M::lim_solimp[j][3], M::lim_solimp[j][4], dist - M::lim_margin[j]);
                     const T R = t_max(T(kMinVal), (T(1.0) - imp) * M::dof_invweight0[j] / imp);
-                    const int li = TP::lim_rank(j);
-                    mem.st(LY::OL + 2 * li, T(1.0) / R);
+                    const int li = TP::T.lim_rank[j];
+                    mem.st(LY::OL + 2 * li, t_rcp(R));
                     mem.st(LY::OL + 2 * li + 1,
                            -M::lim_B[j] * (sg * vj[k]) - M::lim_K[j] * imp * (dist - M::lim_margin[j]));
                     lim_on |= (1u << j);
@@ -365,15 +420,15 @@ struct Lean {
                             if (nslot >= K) { status |= ST_OVERFLOW; continue; }
                             const T Pa = ea, Pb = eb - (M::g_rad[g] + T(0.5) * dist);
                             const T pm = dist - M::c_margin[g];
-                            const double *si = M::c_solimp[g];
-                            const T imp = impedance(si[0], si[1], si[2], si[3], si[4], pm);
+                            const T imp = impedance(M::c_solimp[g][0], M::c_solimp[g][1], M::c_solimp[g][2],
+                                                    M::c_solimp[g][3], M::c_solimp[g][4], pm);
                             const T R = t_max(T(kMinVal), (T(1.0) - imp) * M::c_RK[g] / imp);
                             const T vn = u.b + u.w * Pa, vt = u.a - u.w * Pb;
                             const int o = LY::OS + 5 * nslot;
-                            mem.st(o, Pa); mem.st(o + 1, Pb); mem.st(o + 2, T(1.0) / R);
+                            mem.st(o, Pa); mem.st(o + 1, Pb); mem.st(o + 2, t_rcp(R));
                             mem.st(o + 3, -M::c_B[g] * vn - M::c_K[g] * imp * pm);
                             mem.st(o + 4, -M::c_B[g] * vt);
-                            con_on |= (1u << TP::cand_rank(g, e));
+                            con_on |= (1u << TP::T.cand_rank[g][e]);
                             nslot++;
                         }
                     }
@@ -413,13 +468,13 @@ struct Lean {
                 const T Pa = c1a + na * (M::g_rad[g1] + T(0.5) * dist);
                 const T Pb = c1b + nb * (M::g_rad[g1] + T(0.5) * dist);
                 const T pm = dist - M::pair_margin[k];
-                const double *si = M::pair_solimp[k];
-                const T imp = impedance(si[0], si[1], si[2], si[3], si[4], pm);
+                const T imp = impedance(M::pair_solimp[k][0], M::pair_solimp[k][1], M::pair_solimp[k][2],
+                                        M::pair_solimp[k][3], M::pair_solimp[k][4], pm);
                 const T R = t_max(T(kMinVal), (T(1.0) - imp) * M::pair_RK[k] / imp);
                 const T w0 = nb * Pa - na * Pb;
                 const T vel = w0 * (V[b2].w - V[b1].w) + na * (V[b2].a - V[b1].a) + nb * (V[b2].b - V[b1].b);
                 const int o = LY::OP + 5 * k;
-                mem.st(o, w0); mem.st(o + 1, na); mem.st(o + 2, nb); mem.st(o + 3, T(1.0) / R);
+                mem.st(o, w0); mem.st(o + 1, na); mem.st(o + 2, nb); mem.st(o + 3, t_rcp(R));
                 mem.st(o + 4, -M::pair_B[k] * vel - M::pair_K[k] * imp * pm);
                 pair_on |= (1u << k);
             }
@@ -461,7 +516,7 @@ struct Lean {
                 I.ww = I.ww + aug[b].ww; I.wa = I.wa + aug[b].wa; I.wb = I.wb + aug[b].wb;
                 I.aa = I.aa + aug[b].aa; I.ab = I.ab + aug[b].ab; I.bb = I.bb + aug[b].bb;
             }
-            if (TP::any_child(b)) {   // children were folded into Ic[b] already
+            if (TP::T.any_child[b]) {   // children were folded into Ic[b] already
                 I.ww = I.ww + Ic[b].ww; I.wa = I.wa + Ic[b].wa; I.wb = I.wb + Ic[b].wb;
                 I.aa = I.aa + Ic[b].aa; I.ab = I.ab + Ic[b].ab; I.bb = I.bb + Ic[b].bb;
             }
@@ -479,7 +534,7 @@ struct Lean {
                 }
                 MBRL_UNROLL
                 for (int j = 0; j <= i; j++) {
-                    if (!TP::dof_anc(j, i)) continue;
+                    if (!TP::T.dof_anc[j][i]) continue;
                     T h;
                     if (M::dof_type[j] == 0) h = Fi.a;
                     else if (M::dof_type[j] == 1) h = Fi.b;
@@ -490,7 +545,7 @@ struct Lean {
             }
             if (M::parent[b] >= 0) {
                 const int p = M::parent[b];
-                if (TP::first_folded(b)) Ic[p] = I;
+                if (TP::T.first_folded[b]) Ic[p] = I;
                 else {
                     Ic[p].ww = Ic[p].ww + I.ww; Ic[p].wa = Ic[p].wa + I.wa; Ic[p].wb = Ic[p].wb + I.wb;
                     Ic[p].aa = Ic[p].aa + I.aa; Ic[p].ab = Ic[p].ab + I.ab; Ic[p].bb = Ic[p].bb + I.bb;
@@ -505,14 +560,14 @@ struct Lean {
         MBRL_UNROLL
         for (int k = NV - 1; k >= 0; k--) {
             if (!(t_val(H[k][k]) > 0.0)) ok = false;
-            const T inv = T(1.0) / H[k][k];
+            const T inv = t_rcp(H[k][k]);
             MBRL_UNROLL
             for (int i = k - 1; i >= 0; i--) {
-                if (!TP::dof_anc(i, k)) continue;
+                if (!TP::T.dof_anc[i][k]) continue;
                 const T a = H[k][i] * inv;
                 MBRL_UNROLL
                 for (int j = i; j >= 0; j--) {
-                    if (!TP::dof_anc(j, i)) continue;
+                    if (!TP::T.dof_anc[j][i]) continue;
                     H[i][j] = H[i][j] - a * H[k][j];
                 }
                 H[k][i] = a;
@@ -527,7 +582,7 @@ struct Lean {
         for (int i = NV - 1; i >= 0; i--) {
             MBRL_UNROLL
             for (int j = i - 1; j >= 0; j--)
-                if (TP::dof_anc(j, i)) x[j] = x[j] - H[i][j] * x[i];
+                if (TP::T.dof_anc[j][i]) x[j] = x[j] - H[i][j] * x[i];
         }
         MBRL_UNROLL
         for (int i = 0; i < NV; i++) x[i] = x[i] * H[i][i];
@@ -535,7 +590,7 @@ struct Lean {
         for (int i = 0; i < NV; i++) {
             MBRL_UNROLL
             for (int j = i - 1; j >= 0; j--)
-                if (TP::dof_anc(j, i)) x[i] = x[i] - H[i][j] * x[j];
+                if (TP::T.dof_anc[j][i]) x[i] = x[i] - H[i][j] * x[j];
         }
     }
 
@@ -552,7 +607,7 @@ struct Lean {
         for (int j = 0; j < NV; j++) {
             if (!M::limited[j]) continue;
             if (lim_on & (1u << j)) {
-                const int li = TP::lim_rank(j);
+                const int li = TP::T.lim_rank[j];
                 const T D = mem.ld(LY::OL + 2 * li), aref = mem.ld(LY::OL + 2 * li + 1);
                 const bool up = (lim_hi >> j) & 1u;
                 const T jar = (up ? -x[j] : x[j]) - aref;
@@ -586,7 +641,7 @@ struct Lean {
             const int b = M::g_body[g];
             MBRL_UNROLL
             for (int e = 0; e < 2; e++) {
-                const int cb = TP::cand_rank(g, e);
+                const int cb = TP::T.cand_rank[g][e];
                 if (con_on & (1u << cb)) {
                     const int sl = slot_of(cb), o = LY::OS + 5 * sl;
                     const T Pa = mem.ld(o), Pb = mem.ld(o + 1), D = mem.ld(o + 2);
@@ -638,7 +693,7 @@ struct Lean {
         for (int j = 0; j < NV; j++) {
             if (!M::limited[j]) continue;
             if (lim_on & (1u << j)) {
-                const int li = TP::lim_rank(j);
+                const int li = TP::T.lim_rank[j];
                 const T D = mem.ld(LY::OL + 2 * li), aref = mem.ld(LY::OL + 2 * li + 1);
                 const bool up = (lim_hi >> j) & 1u;
                 const T jar = (up ? -x[j] : x[j]) - aref, jv = up ? -sx[j] : sx[j];
@@ -665,7 +720,7 @@ struct Lean {
             const int b = M::g_body[gi];
             MBRL_UNROLL
             for (int e = 0; e < 2; e++) {
-                const int cb = TP::cand_rank(gi, e);
+                const int cb = TP::T.cand_rank[gi][e];
                 if (con_on & (1u << cb)) {
                     const int sl = slot_of(cb), o = LY::OS + 5 * sl;
                     const T Pa = mem.ld(o), Pb = mem.ld(o + 1), D = mem.ld(o + 2);
@@ -703,16 +758,16 @@ struct Lean {
                 T rr[NV];
                 MBRL_UNROLL
                 for (int j = 0; j < NV; j++) {
-                    if (!(TP::body_anc(M::dof_body[j], b2) && !TP::body_anc(M::dof_body[j], b1))) continue;
+                    if (!TP::T.between[k][j]) continue;
                     const Sp<T> Sj = Scol(j);
                     rr[j] = w0 * Sj.w + w1 * Sj.a + w2 * Sj.b;
                 }
                 MBRL_UNROLL
                 for (int i = 0; i < NV; i++) {
-                    if (!(TP::body_anc(M::dof_body[i], b2) && !TP::body_anc(M::dof_body[i], b1))) continue;
+                    if (!TP::T.between[k][i]) continue;
                     MBRL_UNROLL
                     for (int j = 0; j <= i; j++) {
-                        if (!(TP::body_anc(M::dof_body[j], b2) && !TP::body_anc(M::dof_body[j], b1))) continue;
+                        if (!TP::T.between[k][j]) continue;
                         H[i][j] = H[i][j] + D * rr[i] * rr[j];
                     }
                 }
@@ -729,6 +784,7 @@ struct Lean {
         if (lim_on == 0 && con_on == 0 && pair_on == 0) return;
         uint32_t plm = ~0u, pcm = ~0u;
         bool converged = false;
+        MBRL_NOUNROLL
         for (int it = 0; it <= kMaxNewton; it++) {
             Sp<T> Va[NB], Fc[NB];
             Sym3 aug[NB];
@@ -800,6 +856,7 @@ struct Lean {
             for (int j = 0; j < NV; j++) a2 = a2 + M::arma[j] * sx[j] * sx[j];
             T alpha = T(1.0), lo = T(0.0), hi = T(-1.0);  // hi < 0: no upper bracket yet
             uint32_t llm = lm, lcm = cm;                   // active set the current alpha was derived from
+            MBRL_NOUNROLL
             for (int ls = 0; ls < kMaxLineSearch; ls++) {
                 T g = a1 + alpha * a2, h = a2;
                 uint32_t nlm, ncm;
@@ -869,6 +926,7 @@ struct Lean {
             q0[j] = mem.ld(LY::OQ + j); v0[j] = mem.ld(LY::OV + j);
             aq[j] = T(1.0 / 6) * v0[j]; av[j] = T(1.0 / 6) * qacc[j];
         }
+        MBRL_NOUNROLL
         for (int i = 1; i < 4; i++) {
             const double ai = (i == 3) ? 1.0 : 0.5, bi = (i == 3) ? 1.0 / 6 : 1.0 / 3;
             MBRL_UNROLL
@@ -890,6 +948,7 @@ struct Lean {
     MBRL_HD T env_step(int frame_skip) {
         const T xb = mem.ld(LY::OQ);
         const double dt = M::DT * frame_skip;
+        MBRL_NOUNROLL
         for (int k = 0; k < frame_skip; k++) step();
         T asq = T(0.0);
         MBRL_UNROLL

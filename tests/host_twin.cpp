@@ -33,7 +33,9 @@ inline Cnt t_sqrt(Cnt a) { Cnt::n++; return Cnt(sqrt(a.x)); }
 inline Cnt t_pow(Cnt a, Cnt b) { Cnt::n++; return Cnt(pow(a.x, b.x)); }
 inline Cnt t_fmod(Cnt a, Cnt b) { Cnt::n++; return Cnt(fmod(a.x, b.x)); }
 inline Cnt t_cos(Cnt a) { Cnt::n++; return Cnt(cos(a.x)); }
-inline void t_sincos(Cnt a, Cnt *s, Cnt *c) { Cnt::n += 2; s->x = sin(a.x); c->x = cos(a.x); }
+inline Cnt t_fma(Cnt a, Cnt b, Cnt c) { Cnt::n += 2; return Cnt(__builtin_fma(a.x, b.x, c.x)); }
+inline Cnt t_rint(Cnt a) { return Cnt(__builtin_rint(a.x)); }
+inline Cnt t_rcp(Cnt a) { Cnt::n++; return Cnt(1.0 / a.x); }
 inline bool t_finite(Cnt a) { return a.x - a.x == 0.0; }
 inline double t_val(Cnt a) { return a.x; }
 }  // namespace mbrl

@@ -1,14 +1,21 @@
-"""Summarise rocprofv3 counter CSVs: per kernel name, mean counter value per dispatch."""
+"""Summarise rocprofv3 counter CSVs for the FD launches (the dispatches with the largest grid)."""
 import csv, glob, os, sys, collections
 root = sys.argv[1]
-acc = collections.defaultdict(lambda: collections.defaultdict(list))
+acc = collections.defaultdict(list)
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
-    for r in csv.DictReader(open(f)):
-        k = r.get("Kernel_Name", "?")[:60]
-        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    rows = [r for r in csv.DictReader(open(f)) if "rollout_kernel" in r.get("Kernel_Name", "")]
+    if not rows: continue
+    gmax = max(int(r["Grid_Size"]) for r in rows)
+    for r in rows:
+        if int(r["Grid_Size"]) == gmax:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(os.path.join(root, "summary.txt"), "w") as fh:
-    for k, d in acc.items():
-        if "rollout_kernel" not in k: continue
-        for c, v in sorted(d.items()):
-            line = "%-62s %-28s n=%-4d mean=%.6g" % (k, c, len(v), sum(v) / len(v))
-            print(line); fh.write(line + "\n")
+    for c, v in sorted(acc.items()):
+        line = "%-28s n=%-4d mean=%.6g" % (c, len(v), sum(v) / len(v))
+        print(line); fh.write(line + "\n")
+    w = acc.get("SQ_WAVES", [0])[0]
+    if w:
+        for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM", "SQ_INSTS_BRANCH", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+            if c in acc:
+                line = "per-wave %-24s %.1f" % (c, sum(acc[c]) / len(acc[c]) / w)
+                print(line); fh.write(line + "\n")
