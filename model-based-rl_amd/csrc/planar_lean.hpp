@@ -41,6 +41,16 @@
 #endif
 #define MBRL_UNROLL _Pragma("unroll")
 #define MBRL_NOUNROLL _Pragma("nounroll")
+// Compiler-only memory barrier at the top of the solver loops: without it the loop-invariant LDS loads
+// (limit / contact rows) are hoisted out of the loops and held in registers, which defeats the point
+// of keeping those rows in LDS.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MBRL_LOOP_FENCE asm volatile("" ::: "memory")
+#define MBRL_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define MBRL_LOOP_FENCE
+#define MBRL_OPAQUE(x)
+#endif
 
 namespace mbrl {
 
@@ -169,8 +179,9 @@ struct Layout {
     static constexpr int NV = M::NV, NU = M::NU;
     static constexpr int NLIM = TP::T.nlim, NCAND = TP::T.ncand;
     static constexpr int K = NCAND < 8 ? NCAND : 8;            // contact slots (active rows beyond K: ST_OVERFLOW)
-    static constexpr int OQ = 0, OV = NV, OC = 2 * NV, OL = 2 * NV + NU, OP = OL + 2 * NLIM;
-    static constexpr int OS = OP + 5 * M::NPAIR, NMEM = OS + 5 * K;
+    // contact slots first: their (lane-dependent) addresses are then  base + slot * stride + small immediate
+    static constexpr int OS = 0, OP = 5 * K, OL = OP + 5 * M::NPAIR, OQ = OL + 2 * NLIM, OV = OQ + NV, OC = OV + NV;
+    static constexpr int NMEM = OC + NU;
 };
 
 template <class M, class T, class Mem>
@@ -179,7 +190,7 @@ struct Lean {
     using TP = Topo<M>;
     using LY = Layout<M>;
     static constexpr int K = LY::K;
-    static_assert(3 * K <= 32 && NV + M::NPAIR <= 32 && LY::NCAND <= 32, "row masks are 32-bit");
+    static_assert(3 * K <= 32 && NV + M::NPAIR <= 32 && LY::NCAND <= 16 && K <= 14, "row masks are 32-bit, slot map is 2 x 8 nibbles");
 
     Mem mem;
     // ---- position-dependent, alive through a dynamics evaluation ----
@@ -188,7 +199,7 @@ struct Lean {
     T fsm[NV], qacc[NV], fcon[NV];
     T site_a, site_b;
     uint32_t lim_on, lim_hi;             // bit j: limit row of dof j active / it is the upper limit
-    uint32_t con_on;                     // bit = floor candidate (capsule end) that owns a slot
+    uint32_t smap0, smap1;               // slot map: nibble c = 1 + slot of floor candidate (capsule end) c, 0 = not in contact
     uint32_t pair_on;
     unsigned status;
     int newton_iters;
@@ -277,7 +288,7 @@ struct Lean {
     // kinematics + body velocities + Newton-Euler forward recursion + constraint detection.
     // Leaves: ra, rb, ha, hb, IO, site, constraint rows in `mem`, and the per-body net forces F.
     MBRL_HD void sweep(Sp<T> *F) {
-        lim_on = 0; lim_hi = 0; con_on = 0; pair_on = 0;
+        lim_on = 0; lim_hi = 0; smap0 = 0; smap1 = 0; pair_on = 0;
         int nslot = 0;
         T pa[NB], pb[NB], c[NB], s[NB];
         Sp<T> V[NB], A[NB];
@@ -428,8 +439,10 @@ struct Lean {
                             mem.st(o, Pa); mem.st(o + 1, Pb); mem.st(o + 2, t_rcp(R));
                             mem.st(o + 3, -M::c_B[g] * vn - M::c_K[g] * imp * pm);
                             mem.st(o + 4, -M::c_B[g] * vt);
-                            con_on |= (1u << TP::T.cand_rank[g][e]);
                             nslot++;
+                            const int cb = TP::T.cand_rank[g][e];
+                            if (cb < 8) smap0 |= uint32_t(nslot) << (4 * cb);
+                            else smap1 |= uint32_t(nslot) << (4 * (cb - 8));
                         }
                     }
                 }
@@ -503,19 +516,15 @@ struct Lean {
     // ------------------------------------------------------------------ CRBA on 3x3 symmetric inertias
     struct Sym3 { T ww, wa, wb, aa, ab, bb; };
 
-    // H (lower triangle, tree-sparse) = sum_b A_b^T (I_b + aug_b) A_b + diag(add).  Bodies are folded
-    // leaf-to-root and a body's rows are emitted as soon as its subtree is complete, so at most one
-    // composite per tree level is alive.  aug may be null (plain mass matrix).
-    MBRL_HD void crba(const Sym3 *aug, T (*H)[NV], const T *diag_add) const {
+    // H (lower triangle, tree-sparse) = sum_b A_b^T I_b A_b + diag(add).  Bodies are folded leaf-to-root
+    // and a body's rows are emitted as soon as its subtree is complete, so at most one composite per
+    // tree level is alive.
+    MBRL_HD void crba(T (*H)[NV], const T *diag_add) const {
         Sym3 Ic[NB];
         MBRL_UNROLL
         for (int b = NB - 1; b >= 0; b--) {
             Sym3 I;
             I.ww = IO[b]; I.wa = -hb[b]; I.wb = ha[b]; I.aa = T(M::mass[b]); I.ab = T(0.0); I.bb = T(M::mass[b]);
-            if (aug) {
-                I.ww = I.ww + aug[b].ww; I.wa = I.wa + aug[b].wa; I.wb = I.wb + aug[b].wb;
-                I.aa = I.aa + aug[b].aa; I.ab = I.ab + aug[b].ab; I.bb = I.bb + aug[b].bb;
-            }
             if (TP::T.any_child[b]) {   // children were folded into Ic[b] already
                 I.ww = I.ww + Ic[b].ww; I.wa = I.wa + Ic[b].wa; I.wb = I.wb + Ic[b].wb;
                 I.aa = I.aa + Ic[b].aa; I.ab = I.ab + Ic[b].ab; I.bb = I.bb + Ic[b].bb;
@@ -597,92 +606,149 @@ struct Lean {
     // ------------------------------------------------------------------ constraint rows
     // Row bookkeeping: `lm` bit j = limit row of dof j, bit NV+k = pair row k; `cm` bit 3*slot+r =
     // row r of the contact in that slot (pyramid: n + mu t, n - mu t, n (weight 2); condim 1: r = 2).
-    MBRL_HD int slot_of(int cand_bit) const { return __builtin_popcount(con_on & ((1u << cand_bit) - 1u)); }
+    // 1 + slot of floor candidate c (0: not in contact)
+    MBRL_HD int slot1_of(int c) const { return int(((c < 8 ? smap0 : smap1) >> (4 * (c & 7))) & 15u); }
 
-    // residuals at x = qacc: active masks, constraint forces per body, Hessian augmentation, limit terms
-    MBRL_HD void grad_pass(const Sp<T> *Va, const T *x, Sp<T> *Fc, Sym3 *aug, T *flim, T *hdiag,
-                           uint32_t &lm, uint32_t &cm) const {
+    // One leaf-to-root pass per Newton iteration: constraint residuals at x = qacc (body velocities Va),
+    // the active-row masks, J^T f, and the Newton Hessian  M + arm + J^T D J  (lower triangle) -- contact
+    // rows augment their body's inertia (D w w^T) and force (f w) before the body is folded into its
+    // parent, so no per-body arrays of augmentations or forces exist.
+    MBRL_HD void newton_pass(const Sp<T> *Va, const T *x, T (*H)[NV], T *jtf, uint32_t &lm, uint32_t &cm) const {
         lm = 0; cm = 0;
-        MBRL_UNROLL
-        for (int j = 0; j < NV; j++) {
-            if (!M::limited[j]) continue;
-            if (lim_on & (1u << j)) {
-                const int li = TP::T.lim_rank[j];
-                const T D = mem.ld(LY::OL + 2 * li), aref = mem.ld(LY::OL + 2 * li + 1);
-                const bool up = (lim_hi >> j) & 1u;
-                const T jar = (up ? -x[j] : x[j]) - aref;
-                if (t_val(jar) < 0.0) {
-                    lm |= 1u << j;
-                    const T f = -D * jar;
-                    flim[j] = up ? -f : f;
-                    hdiag[j] = hdiag[j] + D;
-                }
-            }
-        }
-        MBRL_UNROLL
-        for (int k = 0; k < M::NPAIR; k++) {
-            if (pair_on & (1u << k)) {
-                const int b1 = M::g_body[M::pair_g1[k]], b2 = M::g_body[M::pair_g2[k]];
-                const int o = LY::OP + 5 * k;
-                const T w0 = mem.ld(o), w1 = mem.ld(o + 1), w2 = mem.ld(o + 2), D = mem.ld(o + 3), aref = mem.ld(o + 4);
-                const T jar = (w0 * (Va[b2].w - Va[b1].w) + w1 * (Va[b2].a - Va[b1].a) + w2 * (Va[b2].b - Va[b1].b)) - aref;
-                if (t_val(jar) < 0.0) {
-                    lm |= 1u << (NV + k);
-                    const T f = -D * jar;
-                    Fc[b2].w = Fc[b2].w + f * w0; Fc[b2].a = Fc[b2].a + f * w1; Fc[b2].b = Fc[b2].b + f * w2;
-                    Fc[b1].w = Fc[b1].w - f * w0; Fc[b1].a = Fc[b1].a - f * w1; Fc[b1].b = Fc[b1].b - f * w2;
-                }
-            }
-        }
-        if (!M::HAS_FLOOR) return;
-        MBRL_UNROLL
-        for (int g = 0; g < M::NGEOM; g++) {
-            if (!M::c_on[g]) continue;
-            const int b = M::g_body[g];
+        Sp<T> Fp[NB];          // pair-row forces per body (models with capsule/capsule pairs only)
+        if (M::NPAIR > 0) {
             MBRL_UNROLL
-            for (int e = 0; e < 2; e++) {
-                const int cb = TP::T.cand_rank[g][e];
-                if (con_on & (1u << cb)) {
-                    const int sl = slot_of(cb), o = LY::OS + 5 * sl;
-                    const T Pa = mem.ld(o), Pb = mem.ld(o + 1), D = mem.ld(o + 2);
-                    const T rn = (Va[b].b + Va[b].w * Pa) - mem.ld(o + 3);
-                    const T rt = (Va[b].a - Va[b].w * Pb) - mem.ld(o + 4);
-                    // accumulated row weights: force f on w = wn*(Pa,0,1) + wt*(-Pb,1,0); Hessian D w w^T
-                    T fn = T(0.0), ft = T(0.0), dnn = T(0.0), dnt = T(0.0), dtt = T(0.0);
-                    if (M::c_dim[g] == 1) {
-                        if (t_val(rn) < 0.0) { cm |= 1u << (3 * sl + 2); fn = -D * rn; dnn = D; }
-                    } else {
-                        const double mu = M::c_mu[g];
-                        const T r0 = rn + mu * rt, r1 = rn - mu * rt;
-                        if (t_val(r0) < 0.0) {
-                            cm |= 1u << (3 * sl);
-                            const T f = -D * r0;
-                            fn = fn + f; ft = ft + mu * f; dnn = dnn + D; dnt = dnt + mu * D; dtt = dtt + (mu * mu) * D;
-                        }
-                        if (t_val(r1) < 0.0) {
-                            cm |= 1u << (3 * sl + 1);
-                            const T f = -D * r1;
-                            fn = fn + f; ft = ft - mu * f; dnn = dnn + D; dnt = dnt - mu * D; dtt = dtt + (mu * mu) * D;
-                        }
-                        if (t_val(rn) < 0.0) {
-                            cm |= 1u << (3 * sl + 2);
-                            const T D2 = T(2.0) * D;
-                            fn = fn - D2 * rn; dnn = dnn + D2;
-                        }
-                    }
-                    if (cm & (7u << (3 * sl))) {
-                        // n-direction (Pa, 0, 1), t-direction (-Pb, 1, 0)
-                        Fc[b].w = Fc[b].w + (fn * Pa - ft * Pb); Fc[b].a = Fc[b].a + ft; Fc[b].b = Fc[b].b + fn;
-                        if (aug) {
-                            aug[b].ww = aug[b].ww + ((dnn * Pa) * Pa - T(2.0) * (dnt * Pa) * Pb + (dtt * Pb) * Pb);
-                            aug[b].wa = aug[b].wa + (dnt * Pa - dtt * Pb);
-                            aug[b].wb = aug[b].wb + (dnn * Pa - dnt * Pb);
-                            aug[b].aa = aug[b].aa + dtt; aug[b].ab = aug[b].ab + dnt; aug[b].bb = aug[b].bb + dnn;
-                        }
+            for (int b = 0; b < NB; b++) { Fp[b].w = T(0.0); Fp[b].a = T(0.0); Fp[b].b = T(0.0); }
+            MBRL_UNROLL
+            for (int k = 0; k < M::NPAIR; k++) {
+                if (pair_on & (1u << k)) {
+                    const int b1 = M::g_body[M::pair_g1[k]], b2 = M::g_body[M::pair_g2[k]];
+                    const int o = LY::OP + 5 * k;
+                    const T w0 = mem.ld(o), w1 = mem.ld(o + 1), w2 = mem.ld(o + 2), D = mem.ld(o + 3), aref = mem.ld(o + 4);
+                    const T jar = (w0 * (Va[b2].w - Va[b1].w) + w1 * (Va[b2].a - Va[b1].a) + w2 * (Va[b2].b - Va[b1].b)) - aref;
+                    if (t_val(jar) < 0.0) {
+                        lm |= 1u << (NV + k);
+                        const T f = -D * jar;
+                        Fp[b2].w = Fp[b2].w + f * w0; Fp[b2].a = Fp[b2].a + f * w1; Fp[b2].b = Fp[b2].b + f * w2;
+                        Fp[b1].w = Fp[b1].w - f * w0; Fp[b1].a = Fp[b1].a - f * w1; Fp[b1].b = Fp[b1].b - f * w2;
                     }
                 }
             }
         }
+        Sym3 Ic[NB];
+        Sp<T> Fs[NB];
+        MBRL_UNROLL
+        for (int b = NB - 1; b >= 0; b--) {
+            Sym3 I;
+            I.ww = IO[b]; I.wa = -hb[b]; I.wb = ha[b]; I.aa = T(M::mass[b]); I.ab = T(0.0); I.bb = T(M::mass[b]);
+            Sp<T> Fc;
+            if (M::NPAIR > 0) Fc = Fp[b];
+            else { Fc.w = T(0.0); Fc.a = T(0.0); Fc.b = T(0.0); }
+            // ---- floor contacts of this body's capsules ----
+            if (M::HAS_FLOOR) {
+                MBRL_UNROLL
+                for (int g = 0; g < M::NGEOM; g++) {
+                    if (M::g_body[g] != b || !M::c_on[g]) continue;
+                    MBRL_UNROLL
+                    for (int e = 0; e < 2; e++) {
+                        const int s1 = slot1_of(TP::T.cand_rank[g][e]);
+                        if (s1) {
+                            const int sl = s1 - 1, o = LY::OS + 5 * sl;
+                            const T Pa = mem.ld(o), Pb = mem.ld(o + 1), D = mem.ld(o + 2);
+                            const T rn = (Va[b].b + Va[b].w * Pa) - mem.ld(o + 3);
+                            const T rt = (Va[b].a - Va[b].w * Pb) - mem.ld(o + 4);
+                            // accumulated row weights: force f on w = wn*(Pa,0,1) + wt*(-Pb,1,0); Hessian D w w^T
+                            T fn = T(0.0), ft = T(0.0), dnn = T(0.0), dnt = T(0.0), dtt = T(0.0);
+                            uint32_t rows = 0;
+                            if (M::c_dim[g] == 1) {
+                                if (t_val(rn) < 0.0) { rows = 4u; fn = -D * rn; dnn = D; }
+                            } else {
+                                const double mu = M::c_mu[g];
+                                const T r0 = rn + mu * rt, r1 = rn - mu * rt;
+                                if (t_val(r0) < 0.0) {
+                                    rows |= 1u;
+                                    const T f = -D * r0;
+                                    fn = fn + f; ft = ft + mu * f; dnn = dnn + D; dnt = dnt + mu * D; dtt = dtt + (mu * mu) * D;
+                                }
+                                if (t_val(r1) < 0.0) {
+                                    rows |= 2u;
+                                    const T f = -D * r1;
+                                    fn = fn + f; ft = ft - mu * f; dnn = dnn + D; dnt = dnt - mu * D; dtt = dtt + (mu * mu) * D;
+                                }
+                                if (t_val(rn) < 0.0) {
+                                    rows |= 4u;
+                                    const T D2 = T(2.0) * D;
+                                    fn = fn - D2 * rn; dnn = dnn + D2;
+                                }
+                            }
+                            if (rows) {
+                                cm |= rows << (3 * sl);
+                                // n-direction (Pa, 0, 1), t-direction (-Pb, 1, 0)
+                                Fc.w = Fc.w + (fn * Pa - ft * Pb); Fc.a = Fc.a + ft; Fc.b = Fc.b + fn;
+                                I.ww = I.ww + ((dnn * Pa) * Pa - T(2.0) * (dnt * Pa) * Pb + (dtt * Pb) * Pb);
+                                I.wa = I.wa + (dnt * Pa - dtt * Pb);
+                                I.wb = I.wb + (dnn * Pa - dnt * Pb);
+                                I.aa = I.aa + dtt; I.ab = I.ab + dnt; I.bb = I.bb + dnn;
+                            }
+                        }
+                    }
+                }
+            }
+            if (TP::T.any_child[b]) {   // children were folded into Ic[b], Fs[b] already
+                I.ww = I.ww + Ic[b].ww; I.wa = I.wa + Ic[b].wa; I.wb = I.wb + Ic[b].wb;
+                I.aa = I.aa + Ic[b].aa; I.ab = I.ab + Ic[b].ab; I.bb = I.bb + Ic[b].bb;
+                Fc.w = Fc.w + Fs[b].w; Fc.a = Fc.a + Fs[b].a; Fc.b = Fc.b + Fs[b].b;
+            }
+            MBRL_UNROLL
+            for (int k = M::dofnum[b] - 1; k >= 0; k--) {
+                const int i = M::dofadr[b] + k;
+                const Sp<T> S = Scol(i);
+                T diag = T(M::arma[i]), fl = T(0.0);
+                if (M::limited[i]) {
+                    if (lim_on & (1u << i)) {
+                        const int li = TP::T.lim_rank[i];
+                        const T D = mem.ld(LY::OL + 2 * li), aref = mem.ld(LY::OL + 2 * li + 1);
+                        const bool up = (lim_hi >> i) & 1u;
+                        const T jar = (up ? -x[i] : x[i]) - aref;
+                        if (t_val(jar) < 0.0) {
+                            lm |= 1u << i;
+                            const T f = -D * jar;
+                            fl = up ? -f : f;
+                            diag = diag + D;
+                        }
+                    }
+                }
+                Sp<T> Fi;
+                if (M::dof_type[i] == 0) { Fi.w = I.wa; Fi.a = I.aa; Fi.b = I.ab; jtf[i] = Fc.a + fl; }
+                else if (M::dof_type[i] == 1) { Fi.w = I.wb; Fi.a = I.ab; Fi.b = I.bb; jtf[i] = Fc.b + fl; }
+                else {
+                    Fi.w = I.ww * S.w + I.wa * S.a + I.wb * S.b;
+                    Fi.a = I.wa * S.w + I.aa * S.a + I.ab * S.b;
+                    Fi.b = I.wb * S.w + I.ab * S.a + I.bb * S.b;
+                    jtf[i] = (S.w * Fc.w + S.a * Fc.a + S.b * Fc.b) + fl;
+                }
+                MBRL_UNROLL
+                for (int j = 0; j <= i; j++) {
+                    if (!TP::T.dof_anc[j][i]) continue;
+                    T h;
+                    if (M::dof_type[j] == 0) h = Fi.a;
+                    else if (M::dof_type[j] == 1) h = Fi.b;
+                    else { const Sp<T> Sj = Scol(j); h = Sj.w * Fi.w + Sj.a * Fi.a + Sj.b * Fi.b; }
+                    if (j == i) h = h + diag;
+                    H[i][j] = h;
+                }
+            }
+            if (M::parent[b] >= 0) {
+                const int p = M::parent[b];
+                if (TP::T.first_folded[b]) { Ic[p] = I; Fs[p] = Fc; }
+                else {
+                    Ic[p].ww = Ic[p].ww + I.ww; Ic[p].wa = Ic[p].wa + I.wa; Ic[p].wb = Ic[p].wb + I.wb;
+                    Ic[p].aa = Ic[p].aa + I.aa; Ic[p].ab = Ic[p].ab + I.ab; Ic[p].bb = Ic[p].bb + I.bb;
+                    Fs[p].w = Fs[p].w + Fc.w; Fs[p].a = Fs[p].a + Fc.a; Fs[p].b = Fs[p].b + Fc.b;
+                }
+            }
+        }
+        pair_hessian(lm, H);
     }
 
     // derivative g and curvature h of the constraint cost along the search direction at step alpha
@@ -720,9 +786,9 @@ struct Lean {
             const int b = M::g_body[gi];
             MBRL_UNROLL
             for (int e = 0; e < 2; e++) {
-                const int cb = TP::T.cand_rank[gi][e];
-                if (con_on & (1u << cb)) {
-                    const int sl = slot_of(cb), o = LY::OS + 5 * sl;
+                const int s1 = slot1_of(TP::T.cand_rank[gi][e]);
+                if (s1) {
+                    const int sl = s1 - 1, o = LY::OS + 5 * sl;
                     const T Pa = mem.ld(o), Pb = mem.ld(o + 1), D = mem.ld(o + 2);
                     const T rn = (Va[b].b + Va[b].w * Pa) - mem.ld(o + 3);
                     const T rt = (Va[b].a - Va[b].w * Pb) - mem.ld(o + 4);
@@ -776,35 +842,28 @@ struct Lean {
     }
 
     // primal Newton with exact line search, run until the active set reproduces itself.
-    // In: qacc = unconstrained acceleration.  Out: qacc, fcon.
+    // In: qacc = unconstrained acceleration (M + arm) qacc = qfrc_smooth.  Out: qacc, fcon.
+    // The smooth part of the gradient, gs = (M + arm) qacc - qfrc_smooth, is carried along the
+    // iteration (0 at the start, += alpha (M + arm) s per step) instead of being re-evaluated.
     MBRL_HD void solve_constraints() {
         MBRL_UNROLL
         for (int j = 0; j < NV; j++) fcon[j] = T(0.0);
         newton_iters = 0;
-        if (lim_on == 0 && con_on == 0 && pair_on == 0) return;
+        if (lim_on == 0 && (smap0 | smap1) == 0 && pair_on == 0) return;
         uint32_t plm = ~0u, pcm = ~0u;
         bool converged = false;
+        T gs[NV];
+        MBRL_UNROLL
+        for (int j = 0; j < NV; j++) gs[j] = T(0.0);
         MBRL_NOUNROLL
         for (int it = 0; it <= kMaxNewton; it++) {
-            Sp<T> Va[NB], Fc[NB];
-            Sym3 aug[NB];
-            T flim[NV], hdiag[NV];
-            vel_pass(qacc, Va);
-            MBRL_UNROLL
-            for (int b = 0; b < NB; b++) {
-                Fc[b].w = T(0.0); Fc[b].a = T(0.0); Fc[b].b = T(0.0);
-                aug[b].ww = T(0.0); aug[b].wa = T(0.0); aug[b].wb = T(0.0);
-                aug[b].aa = T(0.0); aug[b].ab = T(0.0); aug[b].bb = T(0.0);
-            }
-            MBRL_UNROLL
-            for (int j = 0; j < NV; j++) { flim[j] = T(0.0); hdiag[j] = T(M::arma[j]); }
+            MBRL_LOOP_FENCE;
+            MBRL_OPAQUE(smap0); MBRL_OPAQUE(smap1); MBRL_OPAQUE(lim_on);   // keep the per-row bit tests inside the loop
+            Sp<T> Va[NB];
+            T H[NV][NV], jtf[NV], sx[NV];
             uint32_t lm, cm;
-            grad_pass(Va, qacc, Fc, aug, flim, hdiag, lm, cm);
-            // constraint force at the current point
-            T jtf[NV];
-            back_pass(Fc, jtf);
-            MBRL_UNROLL
-            for (int j = 0; j < NV; j++) jtf[j] = jtf[j] + flim[j];
+            vel_pass(qacc, Va);
+            newton_pass(Va, qacc, H, jtf, lm, cm);
             if ((lm == plm && cm == pcm) || it == kMaxNewton) {
                 converged = (lm == plm && cm == pcm);
                 MBRL_UNROLL
@@ -813,29 +872,14 @@ struct Lean {
             }
             plm = lm; pcm = cm;
             newton_iters = it + 1;
-            // gradient  M qacc - qfrc_smooth - J^T f
-            T Ma[NV], sx[NV];
-            {
-                Sp<T> Fm[NB];
-                MBRL_UNROLL
-                for (int b = 0; b < NB; b++) Fm[b] = inert_mul(b, Va[b]);
-                back_pass(Fm, Ma);
-            }
-            T H[NV][NV];
-            crba(aug, H, hdiag);
-            pair_hessian(lm, H);
             const bool ok = factor(H);
             if (!ok) { status |= ST_NONFINITE; break; }
-            T a1 = T(0.0);
             MBRL_UNROLL
-            for (int j = 0; j < NV; j++) {
-                Ma[j] = (Ma[j] + M::arma[j] * qacc[j]) - fsm[j];     // M qacc - qfrc_smooth
-                sx[j] = -(Ma[j] - jtf[j]);
-            }
+            for (int j = 0; j < NV; j++) sx[j] = jtf[j] - gs[j];     // - gradient
             solve(H, sx);
-            T snorm = T(0.0), qnorm = T(0.0);
+            T snorm = T(0.0), qnorm = T(0.0), a1 = T(0.0);
             MBRL_UNROLL
-            for (int j = 0; j < NV; j++) { snorm = snorm + sx[j] * sx[j]; qnorm = qnorm + qacc[j] * qacc[j]; a1 = a1 + sx[j] * Ma[j]; }
+            for (int j = 0; j < NV; j++) { snorm = snorm + sx[j] * sx[j]; qnorm = qnorm + qacc[j] * qacc[j]; a1 = a1 + sx[j] * gs[j]; }
             if (!t_finite(snorm)) { status |= ST_NONFINITE; break; }
             if (t_val(t_sqrt(snorm)) <= 1e-15 * (1.0 + t_val(t_sqrt(qnorm)))) {
                 converged = true;
@@ -845,19 +889,23 @@ struct Lean {
             }
             // exact line search: root of the piecewise-linear derivative (safeguarded Newton)
             Sp<T> Vs[NB];
+            T Ms[NV];
             vel_pass(sx, Vs);
+            {
+                Sp<T> Fm[NB];
+                MBRL_UNROLL
+                for (int b = 0; b < NB; b++) Fm[b] = inert_mul(b, Vs[b]);
+                back_pass(Fm, Ms);
+            }
             T a2 = T(0.0);
             MBRL_UNROLL
-            for (int b = 0; b < NB; b++) {
-                const Sp<T> Is = inert_mul(b, Vs[b]);
-                a2 = a2 + (Vs[b].w * Is.w + Vs[b].a * Is.a + Vs[b].b * Is.b);
-            }
-            MBRL_UNROLL
-            for (int j = 0; j < NV; j++) a2 = a2 + M::arma[j] * sx[j] * sx[j];
+            for (int j = 0; j < NV; j++) { Ms[j] = Ms[j] + M::arma[j] * sx[j]; a2 = a2 + sx[j] * Ms[j]; }
             T alpha = T(1.0), lo = T(0.0), hi = T(-1.0);  // hi < 0: no upper bracket yet
             uint32_t llm = lm, lcm = cm;                   // active set the current alpha was derived from
             MBRL_NOUNROLL
             for (int ls = 0; ls < kMaxLineSearch; ls++) {
+                MBRL_LOOP_FENCE;
+                MBRL_OPAQUE(smap0); MBRL_OPAQUE(smap1); MBRL_OPAQUE(lim_on);
                 T g = a1 + alpha * a2, h = a2;
                 uint32_t nlm, ncm;
                 line_pass(Va, Vs, qacc, sx, alpha, g, h, nlm, ncm);
@@ -870,7 +918,7 @@ struct Lean {
                 alpha = an;
             }
             MBRL_UNROLL
-            for (int j = 0; j < NV; j++) qacc[j] = qacc[j] + alpha * sx[j];
+            for (int j = 0; j < NV; j++) { qacc[j] = qacc[j] + alpha * sx[j]; gs[j] = gs[j] + alpha * Ms[j]; }
         }
         if (!converged) status |= ST_NOCONVERGE;
     }
@@ -882,12 +930,12 @@ struct Lean {
             sweep(F);
             smooth_forces(F);
         }
-        const bool constrained = (lim_on | con_on | pair_on) != 0;
+        const bool constrained = (lim_on | smap0 | smap1 | pair_on) != 0;
         if (M::RK4 || !M::ANY_DAMPING || constrained) {   // Euler with implicit damping needs qacc only for the solver
             T H[NV][NV], arm[NV];
             MBRL_UNROLL
             for (int j = 0; j < NV; j++) { arm[j] = T(M::arma[j]); qacc[j] = fsm[j]; }
-            crba(nullptr, H, arm);
+            crba(H, arm);
             if (!factor(H)) status |= ST_NONFINITE;
             solve(H, qacc);
         }
@@ -901,7 +949,7 @@ struct Lean {
             T H[NV][NV], dg[NV];
             MBRL_UNROLL
             for (int j = 0; j < NV; j++) { dg[j] = T(M::arma[j]) + T(M::DT) * M::damp[j]; x[j] = fsm[j] + fcon[j]; }
-            crba(nullptr, H, dg);
+            crba(H, dg);
             if (!factor(H)) status |= ST_NONFINITE;
             solve(H, x);
         } else {

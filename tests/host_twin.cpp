@@ -63,7 +63,9 @@ static int fwd(const double *q, const double *v, const double *c, double *qacc, 
     h.S.forward();
     for (int j = 0; j < M::NV; j++) { qacc[j] = h.S.qacc[j]; fsm[j] = h.S.fsm[j]; fcon[j] = h.S.fcon[j]; }
     *iters = h.S.newton_iters;
-    *nactive = __builtin_popcount(h.S.con_on);
+    int na = 0;
+    for (int c = 0; c < 16; c++) na += h.S.slot1_of(c) ? 1 : 0;
+    *nactive = na;
     return (int)h.S.status;
 }
 
