@@ -657,39 +657,35 @@ struct Lean {
                             const T Pa = mem.ld(o), Pb = mem.ld(o + 1), D = mem.ld(o + 2);
                             const T rn = (Va[b].b + Va[b].w * Pa) - mem.ld(o + 3);
                             const T rt = (Va[b].a - Va[b].w * Pb) - mem.ld(o + 4);
-                            // accumulated row weights: force f on w = wn*(Pa,0,1) + wt*(-Pb,1,0); Hessian D w w^T
-                            T fn = T(0.0), ft = T(0.0), dnn = T(0.0), dnt = T(0.0), dtt = T(0.0);
-                            uint32_t rows = 0;
+                            // Row weights w = wn*(Pa,0,1) + wt*(-Pb,1,0); force f w, Hessian D w w^T.  Branch-free:
+                            // an inactive row (residual >= 0) contributes min(r, 0) = 0 and D_row = 0.
+                            T fn, ft, dnn, dnt, dtt;
+                            uint32_t rows;
                             if (M::c_dim[g] == 1) {
-                                if (t_val(rn) < 0.0) { rows = 4u; fn = -D * rn; dnn = D; }
+                                const bool on = t_val(rn) < 0.0;
+                                rows = on ? 4u : 0u;
+                                dnn = on ? D : T(0.0);
+                                fn = -D * t_min(rn, T(0.0)); ft = T(0.0); dnt = T(0.0); dtt = T(0.0);
                             } else {
                                 const double mu = M::c_mu[g];
                                 const T r0 = rn + mu * rt, r1 = rn - mu * rt;
-                                if (t_val(r0) < 0.0) {
-                                    rows |= 1u;
-                                    const T f = -D * r0;
-                                    fn = fn + f; ft = ft + mu * f; dnn = dnn + D; dnt = dnt + mu * D; dtt = dtt + (mu * mu) * D;
-                                }
-                                if (t_val(r1) < 0.0) {
-                                    rows |= 2u;
-                                    const T f = -D * r1;
-                                    fn = fn + f; ft = ft - mu * f; dnn = dnn + D; dnt = dnt - mu * D; dtt = dtt + (mu * mu) * D;
-                                }
-                                if (t_val(rn) < 0.0) {
-                                    rows |= 4u;
-                                    const T D2 = T(2.0) * D;
-                                    fn = fn - D2 * rn; dnn = dnn + D2;
-                                }
+                                const bool on0 = t_val(r0) < 0.0, on1 = t_val(r1) < 0.0, on2 = t_val(rn) < 0.0;
+                                rows = (on0 ? 1u : 0u) | (on1 ? 2u : 0u) | (on2 ? 4u : 0u);
+                                const T d0 = on0 ? D : T(0.0), d1 = on1 ? D : T(0.0), d2 = on2 ? T(2.0) * D : T(0.0);
+                                const T m0 = t_min(r0, T(0.0)), m1 = t_min(r1, T(0.0)), m2 = t_min(rn, T(0.0));
+                                fn = -D * ((m0 + m1) + T(2.0) * m2);
+                                ft = (-mu * D) * (m0 - m1);
+                                dnn = (d0 + d1) + d2;
+                                dnt = mu * (d0 - d1);
+                                dtt = (mu * mu) * (d0 + d1);
                             }
-                            if (rows) {
-                                cm |= rows << (3 * sl);
-                                // n-direction (Pa, 0, 1), t-direction (-Pb, 1, 0)
-                                Fc.w = Fc.w + (fn * Pa - ft * Pb); Fc.a = Fc.a + ft; Fc.b = Fc.b + fn;
-                                I.ww = I.ww + ((dnn * Pa) * Pa - T(2.0) * (dnt * Pa) * Pb + (dtt * Pb) * Pb);
-                                I.wa = I.wa + (dnt * Pa - dtt * Pb);
-                                I.wb = I.wb + (dnn * Pa - dnt * Pb);
-                                I.aa = I.aa + dtt; I.ab = I.ab + dnt; I.bb = I.bb + dnn;
-                            }
+                            cm |= rows << (3 * sl);
+                            // n-direction (Pa, 0, 1), t-direction (-Pb, 1, 0)
+                            Fc.w = Fc.w + (fn * Pa - ft * Pb); Fc.a = Fc.a + ft; Fc.b = Fc.b + fn;
+                            I.ww = I.ww + ((dnn * Pa) * Pa - T(2.0) * (dnt * Pa) * Pb + (dtt * Pb) * Pb);
+                            I.wa = I.wa + (dnt * Pa - dtt * Pb);
+                            I.wb = I.wb + (dnn * Pa - dnt * Pb);
+                            I.aa = I.aa + dtt; I.ab = I.ab + dnt; I.bb = I.bb + dnn;
                         }
                     }
                 }
@@ -795,18 +791,19 @@ struct Lean {
                     const T sn = Vs[b].b + Vs[b].w * Pa, st = Vs[b].a - Vs[b].w * Pb;
                     if (M::c_dim[gi] == 1) {
                         const T r = rn + alpha * sn;
-                        if (t_val(r) < 0.0) { cm |= 1u << (3 * sl + 2); g = g + D * r * sn; h = h + D * sn * sn; }
+                        const bool on = t_val(r) < 0.0;
+                        cm |= (on ? 4u : 0u) << (3 * sl);
+                        const T d = on ? D : T(0.0);
+                        g = g + (d * r) * sn; h = h + (d * sn) * sn;
                     } else {
                         const double mu = M::c_mu[gi];
                         const T j0 = sn + mu * st, j1 = sn - mu * st;
                         const T r0 = (rn + mu * rt) + alpha * j0, r1 = (rn - mu * rt) + alpha * j1, r2 = rn + alpha * sn;
-                        if (t_val(r0) < 0.0) { cm |= 1u << (3 * sl); g = g + D * r0 * j0; h = h + D * j0 * j0; }
-                        if (t_val(r1) < 0.0) { cm |= 1u << (3 * sl + 1); g = g + D * r1 * j1; h = h + D * j1 * j1; }
-                        if (t_val(r2) < 0.0) {
-                            cm |= 1u << (3 * sl + 2);
-                            const T D2 = T(2.0) * D;
-                            g = g + D2 * r2 * sn; h = h + D2 * sn * sn;
-                        }
+                        const bool on0 = t_val(r0) < 0.0, on1 = t_val(r1) < 0.0, on2 = t_val(r2) < 0.0;
+                        cm |= ((on0 ? 1u : 0u) | (on1 ? 2u : 0u) | (on2 ? 4u : 0u)) << (3 * sl);
+                        const T d0 = on0 ? D : T(0.0), d1 = on1 ? D : T(0.0), d2 = on2 ? T(2.0) * D : T(0.0);
+                        g = g + (((d0 * r0) * j0 + (d1 * r1) * j1) + (d2 * r2) * sn);
+                        h = h + (((d0 * j0) * j0 + (d1 * j1) * j1) + (d2 * sn) * sn);
                     }
                 }
             }
