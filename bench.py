@@ -25,7 +25,18 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X spec: 256 CU x 4 SIMD x 16 fp64 FMA la
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 ENV = "HalfCheetahEnv"
 BATCH, HORIZON = 4096, 40
-FLOPS_PER_UNIT_RECORDED = 1.05e6  # fallback; re-counted live when the host twin is present
+FLOPS_PER_UNIT_RECORDED = 1.0e6  # fallback; re-counted live when the host twin is present
+
+
+def recorded_traffic(n_units):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json; FETCH_SIZE and
+    WRITE_SIZE collected in separate --pmc runs, KB units, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    for gfx950), scaled to this launch's unit count.  None when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if not os.path.exists(path):
+        return None
+    t = json.load(open(path))
+    return t["hbm_bytes_per_launch"] * n_units / t["units"]
 
 
 def count_flops_per_unit(q, v, c, frame_skip, eps=1e-6):
@@ -81,7 +92,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--units", type=int, default=BATCH * HORIZON)
     ap.add_argument("--fd-mode", type=int, default=0)
-    ap.add_argument("--cpu-units", type=int, default=8192)
+    ap.add_argument("--cpu-units", type=int, default=16384)
     ap.add_argument("--no-cpu", action="store_true")
     a = ap.parse_args()
 
@@ -147,8 +158,8 @@ def main():
                        "env": ENV, "units_per_gpu": N, "frame_skip": 10, "fd_mode": a.fd_mode,
                        "parallelism": "units sharded over %d GPU(s), no data-path collective" % world},
             "roofline": {"bound": "valu_fp64", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "rollout_kernel<MdlHalfCheetah>", "kernel_ms": kern_ms,
+                         "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "traffic": recorded_traffic(N),
+                         "kernel": "rollout_kernel<MdlHalfCheetah, false>", "kernel_ms": kern_ms,
                          "flops_per_unit": fpu, "flops_source": how,
                          "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                  "bytes_per_unit": bytes_unit},

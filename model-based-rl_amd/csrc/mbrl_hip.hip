@@ -32,7 +32,9 @@ constexpr int MODE_FORWARD = 0, MODE_CENTRAL = 1, MODE_STEP = 2;
 // the same machine code and agree bit for bit (the reference asserts exactly that, backward.py:371,374).
 //   mode FORWARD: R = 1 + NP rollouts per unit (NP = nu + nv + nq), CENTRAL: R = 1 + 2 NP, STEP: R = 1.
 // Column order of calculate_gradients: ctrl, then qvel, then qpos (backward.py:389,409,433).
-template <class M>
+// STEP_NAME only gives plain-step launches their own symbol in profiler output (the body does not use it,
+// so both instantiations are compiled from identical IR; tests/test_gpu_parity.py checks the bits).
+template <class M, bool STEP_NAME>
 __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_skip, int nsteps, double eps, int mode,
                                                           const double *__restrict__ qpos,
                                                           const double *__restrict__ qvel,
@@ -255,8 +257,12 @@ static void launch_rollouts(const mbrl_model *m, int64_t N, int mode, const doub
     const int R = mode == MODE_STEP ? 1 : (mode == MODE_CENTRAL ? 1 + 2 * NP : 1 + NP);
     const int upb = kBlock / R;
     const int64_t blocks = (N + upb - 1) / upb;
-    hipLaunchKernelGGL((rollout_kernel<M>), dim3((unsigned)blocks), dim3(kBlock), 0, st, N, m->frame_skip, nsteps, eps,
-                       mode, qpos, qvel, ctrl, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward, status);
+    if (mode == MODE_STEP)
+        hipLaunchKernelGGL((rollout_kernel<M, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, N, m->frame_skip, nsteps,
+                           eps, mode, qpos, qvel, ctrl, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward, status);
+    else
+        hipLaunchKernelGGL((rollout_kernel<M, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, N, m->frame_skip, nsteps,
+                           eps, mode, qpos, qvel, ctrl, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward, status);
 }
 
 extern "C" {
