@@ -19,13 +19,39 @@
 #include <new>
 
 #include "../../include/mbrl.h"
+
+#ifdef MBRL_PHASE_TIMING   // profiling build only (tools/phase_timing.py): shader-clock totals per solver phase
+__device__ unsigned long long g_phase_acc[16];
+__device__ __forceinline__ void mbrl_phase_mark(int k) {
+    static __shared__ unsigned long long last[8];
+    const int w = threadIdx.x >> 6;
+    const unsigned long long now = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) {
+        if (k != 15) atomicAdd(&g_phase_acc[k], now - last[w]);
+        last[w] = now;
+    }
+}
+#define MBRL_PHASE(k) mbrl_phase_mark(k)
+#endif
+
 #include "planar_lean.hpp"
 
 namespace mbrl {
 
-constexpr int kBlock = 256;
+#ifndef MBRL_BLOCK
+#define MBRL_BLOCK 128
+#endif
+constexpr int kBlock = MBRL_BLOCK;
 
 constexpr int MODE_FORWARD = 0, MODE_CENTRAL = 1, MODE_STEP = 2;
+
+#ifdef MBRL_WAVE_TIMING   // profiling build only (tools/wave_timing.py): per-wave shader-clock stamps
+__device__ unsigned long long *g_wave_timing = nullptr;
+#define MBRL_STAMP(k) do { if (g_wave_timing && (threadIdx.x & 63) == 0) \
+    g_wave_timing[(size_t(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6)) * 4 + (k)] = clock64(); } while (0)
+#else
+#define MBRL_STAMP(k)
+#endif
 
 // ONE kernel per model for env.step, forward-difference and central-difference linearisation: the
 // mode is a run-time argument, so the nominal rollout of an FD launch and a plain step launch execute
@@ -60,6 +86,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_sk
     const int64_t unit = unit0 + u;
     stat[t] = 0;
     __syncthreads();
+    MBRL_STAMP(0);
 
     const bool live = u < UPB && unit < N;
     double o[ROW];
@@ -82,14 +109,18 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_sk
 #pragma unroll
         for (int j = 0; j < NV; j++) S.mem.st(LY::OQ + j, idx == NU + NV + j ? qp[j] + d : qp[j]);
         double r = 0.0;
+        MBRL_PHASE(15);
         for (int k = 0; k < nsteps; k++) r = S.env_step(frame_skip);
+        MBRL_PHASE(9);
         S.check_finite();
 #pragma unroll
         for (int j = 0; j < NV; j++) { o[j] = S.mem.ld(LY::OQ + j); o[NV + j] = S.mem.ld(LY::OV + j); }
         o[NS] = r;
         st = S.status;
     }
+    MBRL_STAMP(1);
     __syncthreads();                      // every lane is done with its column: re-use LDS as res
+    MBRL_STAMP(2);
     if (live) {
         double *ro = res + (u * R + p) * ROW;
 #pragma unroll
@@ -159,6 +190,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_sk
         if (reward) reward[unit0 + t] = res[t * R * ROW + NS];
         if (status) status[unit0 + t] = stat[t];
     }
+    MBRL_STAMP(3);
 }
 
 // Backward recurrence of the op chain (mujoco.py:43-104): one thread per (episode, output lane).
@@ -264,6 +296,20 @@ static void launch_rollouts(const mbrl_model *m, int64_t N, int mode, const doub
         hipLaunchKernelGGL((rollout_kernel<M, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, N, m->frame_skip, nsteps,
                            eps, mode, qpos, qvel, ctrl, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward, status);
 }
+
+#ifdef MBRL_PHASE_TIMING
+extern "C" int mbrl_debug_phase_read(unsigned long long *host16, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_phase_acc), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_acc), z, sizeof z); }
+    return rc;
+}
+#endif
+
+#ifdef MBRL_WAVE_TIMING
+extern "C" int mbrl_debug_set_wave_timing(void *buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_timing), &buf, sizeof buf);
+}
+#endif
 
 extern "C" {
 

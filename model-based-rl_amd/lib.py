@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libmbrl_hip.so")
+LIB_PATH = os.environ.get("MBRL_LIB") or os.path.join(HERE, "csrc", "libmbrl_hip.so")   # MBRL_LIB: profiling variants
 
 ST_NONFINITE, ST_NOCONVERGE, ST_OVERFLOW, ST_DEGENERATE = 1, 2, 4, 8
 FD_FORWARD, FD_CENTRAL = 0, 1
