@@ -21,17 +21,19 @@
 #include "../../include/mbrl.h"
 
 #ifdef MBRL_PHASE_TIMING   // profiling build only (tools/phase_timing.py): shader-clock totals per solver phase
+// Light marks: the previous stamp lives in a scalar register pair, the per-wave totals in LDS (fire-and-forget
+// ds_add); phase 10 is a back-to-back pair of marks, i.e. the cost of one mark, for calibration.
 __device__ unsigned long long g_phase_acc[16];
-__device__ __forceinline__ void mbrl_phase_mark(int k) {
-    static __shared__ unsigned long long last[8];
-    const int w = threadIdx.x >> 6;
+__shared__ unsigned long long s_phase_acc[4][16];
+__device__ __forceinline__ void mbrl_phase_mark(int k, unsigned long long &last) {
     const unsigned long long now = __builtin_amdgcn_s_memtime();
-    if ((threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) {
-        if (k != 15) atomicAdd(&g_phase_acc[k], now - last[w]);
-        last[w] = now;
-    }
+    const unsigned long long dt = now - last;
+    last = now;
+    if (k != 15 && (threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
+        atomicAdd(&s_phase_acc[threadIdx.x >> 6][k], dt);
 }
-#define MBRL_PHASE(k) mbrl_phase_mark(k)
+#define MBRL_PHASE(k) mbrl_phase_mark(k, mbrl_phase_last)
+#define MBRL_PHASE_MEMBER unsigned long long mbrl_phase_last;
 #endif
 
 #include "planar_lean.hpp"
@@ -109,9 +111,24 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_sk
 #pragma unroll
         for (int j = 0; j < NV; j++) S.mem.st(LY::OQ + j, idx == NU + NV + j ? qp[j] + d : qp[j]);
         double r = 0.0;
-        MBRL_PHASE(15);
+#ifdef MBRL_PHASE_TIMING
+        {
+            unsigned long long &mbrl_phase_last = S.mbrl_phase_last;
+            for (int k = 0; k < 16; k++) s_phase_acc[threadIdx.x >> 6][k] = 0;
+            MBRL_PHASE(15);
+            MBRL_PHASE(10);
+        }
+#endif
         for (int k = 0; k < nsteps; k++) r = S.env_step(frame_skip);
-        MBRL_PHASE(9);
+#ifdef MBRL_PHASE_TIMING
+        {
+            unsigned long long &mbrl_phase_last = S.mbrl_phase_last;
+            MBRL_PHASE(9);
+            MBRL_PHASE(10);
+            if ((threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
+                for (int k = 0; k < 16; k++) atomicAdd(&g_phase_acc[k], s_phase_acc[threadIdx.x >> 6][k]);
+        }
+#endif
         S.check_finite();
 #pragma unroll
         for (int j = 0; j < NV; j++) { o[j] = S.mem.ld(LY::OQ + j); o[NV + j] = S.mem.ld(LY::OV + j); }

@@ -65,6 +65,7 @@
 // since the previous mark to phase k
 #ifndef MBRL_PHASE
 #define MBRL_PHASE(k)
+#define MBRL_PHASE_MEMBER
 #define MBRL_PIN(p, n)
 #else   // make the n doubles at p materialise here, so that their arithmetic is charged to the phase that owns it
 #define MBRL_PIN(p, n) do { _Pragma("unroll") for (int i_ = 0; i_ < (n); i_++) asm volatile("" : "+v"((p)[i_])); } while (0)
@@ -85,7 +86,9 @@ MBRL_HD double t_sqrt(double x) { return sqrt(x); }
 MBRL_HD double t_pow(double x, double y) { return pow(x, y); }
 MBRL_HD double t_fmod(double x, double y) { return fmod(x, y); }
 MBRL_HD double t_cos(double x) { return cos(x); }
-MBRL_HD bool t_finite(double x) { return x - x == 0.0; }
+MBRL_HD bool t_finite(double x) {   // exponent test on the bits: survives no-NaN / no-infinity compilation
+    return ((__builtin_bit_cast(uint64_t, x) >> 52) & 0x7ffu) != 0x7ffu;
+}
 MBRL_HD double t_val(double x) { return x; }
 MBRL_HD double t_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 MBRL_HD double t_rint(double x) { return __builtin_rint(x); }
@@ -126,6 +129,57 @@ MBRL_HD void t_sincos(T x, T *s, T *c) {
     *c = ((q + 1) & 2) ? -cc : cc;
 }
 
+// sin and cos of N angles at once, coefficient by coefficient: the twelve polynomial constants are then
+// materialised once per batch instead of once per angle (they are scalar-register literals on the device).
+template <class T, int N>
+MBRL_HD void t_sincos_batch(const T *x, T *s, T *c) {
+    static_assert(N >= 1, "");
+    constexpr double SC[6] = {1.58969099521155010221e-10, -2.50507602534068634195e-08, 2.75573137070700676789e-06,
+                              -1.98412698298579493134e-04, 8.33333333332248946124e-03, -1.66666666666666324348e-01};
+    constexpr double CC[6] = {-1.13596475577881948265e-11, 2.08757232129817482790e-09, -2.75573143513906633035e-07,
+                              2.48015872894767294178e-05, -1.38888888888741095749e-03, 4.16666666666666019037e-02};
+    T k[N], r[N], z[N], ps[N], pc[N];
+    MBRL_UNROLL
+    for (int i = 0; i < N; i++) k[i] = t_rint(x[i] * T(6.36619772367581382433e-01));
+    MBRL_UNROLL
+    for (int i = 0; i < N; i++) r[i] = t_fma(-k[i], T(1.5707963267948966), x[i]);
+    MBRL_UNROLL
+    for (int i = 0; i < N; i++) { r[i] = t_fma(-k[i], T(6.123233995736766e-17), r[i]); z[i] = r[i] * r[i]; }
+    MBRL_UNROLL
+    for (int i = 0; i < N; i++) ps[i] = t_fma(z[i], T(SC[0]), T(SC[1]));
+    MBRL_UNROLL
+    for (int m = 2; m < 6; m++) {
+        MBRL_UNROLL
+        for (int i = 0; i < N; i++) ps[i] = t_fma(z[i], ps[i], T(SC[m]));
+    }
+    MBRL_UNROLL
+    for (int i = 0; i < N; i++) pc[i] = t_fma(z[i], T(CC[0]), T(CC[1]));
+    MBRL_UNROLL
+    for (int m = 2; m < 6; m++) {
+        MBRL_UNROLL
+        for (int i = 0; i < N; i++) pc[i] = t_fma(z[i], pc[i], T(CC[m]));
+    }
+    MBRL_UNROLL
+    for (int i = 0; i < N; i++) {
+        const T sr = t_fma(r[i] * z[i], ps[i], r[i]);
+        const T cr = t_fma(z[i] * z[i], pc[i], t_fma(z[i], T(-0.5), T(1.0)));
+        const int q = int(t_val(k[i])) & 3;
+        const T ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
+        s[i] = (q & 2) ? -ss : ss;
+        c[i] = ((q + 1) & 2) ? -cc : cc;
+    }
+}
+
+// (cc*x - ss*y, ss*x + cc*y) for a compile-time constant point (x, y); zero components cost nothing
+// (x * 0.0 is not folded by the compiler: it is not an identity for NaN / infinity)
+template <class T>
+MBRL_HD void t_rot(T cc, T ss, double x, double y, T *oa, T *ob) {
+    if (x == 0.0 && y == 0.0) { *oa = T(0.0); *ob = T(0.0); }
+    else if (y == 0.0) { *oa = cc * x; *ob = ss * x; }
+    else if (x == 0.0) { *oa = -(ss * y); *ob = cc * y; }
+    else { *oa = cc * x - ss * y; *ob = ss * x + cc * y; }
+}
+
 template <class T>
 struct Sp {  // planar spatial vector: angular part w, linear part (a, b)
     T w, a, b;
@@ -155,6 +209,9 @@ struct Topo {
     struct Tables {
         bool dof_anc[NV][NV];     // [j][i]: dof j moves the body of dof i (j <= i in index order)
         int lim_rank[NV];         // index of dof j among the limited dofs
+        int hinge_rank[NV];       // index of dof j among the hinge dofs
+        int hinge_dof[NV];        // its inverse
+        int nhinge;
         int cand_rank[NG][2];     // index of capsule end (g, e) among the floor-contact candidates
         bool any_child[NB];
         bool first_folded[NB];    // b is the highest-index child of its parent (first one a leaf-to-root pass folds)
@@ -169,6 +226,12 @@ struct Topo {
         int n = 0;
         for (int j = 0; j < NV; j++) { t.lim_rank[j] = n; n += M::limited[j] ? 1 : 0; }
         t.nlim = n;
+        n = 0;
+        for (int j = 0; j < NV; j++) {
+            t.hinge_rank[j] = n; t.hinge_dof[j] = 0;
+            if (M::dof_type[j] == 2) { t.hinge_dof[n] = j; n++; }
+        }
+        t.nhinge = n;
         n = 0;
         for (int g = 0; g < NG; g++) {
             t.cand_rank[g][0] = n; t.cand_rank[g][1] = n + 1;
@@ -230,6 +293,7 @@ struct Lean {
     uint32_t pair_on;
     unsigned status;
     int newton_iters;
+    MBRL_PHASE_MEMBER
 
     // ------------------------------------------------------------------ motion subspace
     MBRL_HD Sp<T> Scol(int j) const {
@@ -342,6 +406,17 @@ struct Lean {
         T qall[NV], vall[NV];
         MBRL_UNROLL
         for (int j = 0; j < NV; j++) { qall[j] = mem.ld(LY::OQ + j); vall[j] = mem.ld(LY::OV + j); }
+        constexpr int NH = TP::T.nhinge > 0 ? TP::T.nhinge : 1;
+        T hs[NH], hc[NH];          // sin / cos of every hinge angle, evaluated as one batch
+        {
+            T ang[NH];
+            MBRL_UNROLL
+            for (int i = 0; i < TP::T.nhinge; i++) {
+                const int j = TP::T.hinge_dof[i];
+                ang[i] = M::dof_sgn[j] * (qall[j] - M::qpos0[j]);
+            }
+            if (TP::T.nhinge > 0) t_sincos_batch<T, NH>(ang, hs, hc);
+        }
         T pa[NB], pb[NB], c[NB], s[NB];
         Sp<T> V[NB], A[NB];
         T Ob = T(0.0), Oa = T(0.0);
@@ -353,8 +428,9 @@ struct Lean {
                 px = T(M::bpos[b][0]); py = T(M::bpos[b][1]); cc = T(1.0); ss = T(0.0);
             } else {
                 const int p = M::parent[b];
-                px = pa[p] + (c[p] * M::bpos[b][0] - s[p] * M::bpos[b][1]);
-                py = pb[p] + (s[p] * M::bpos[b][0] + c[p] * M::bpos[b][1]);
+                T da, db;
+                t_rot(c[p], s[p], M::bpos[b][0], M::bpos[b][1], &da, &db);
+                px = pa[p] + da; py = pb[p] + db;
                 cc = c[p]; ss = s[p];
             }
             T qj[3], vj[3], anca[3], ancb[3];
@@ -366,14 +442,14 @@ struct Lean {
                 if (M::dof_type[j] == 0) px = px + dq;
                 else if (M::dof_type[j] == 1) py = py + dq;
                 else {
-                    const T ax = px + (cc * M::jpos[j][0] - ss * M::jpos[j][1]);
-                    const T ay = py + (ss * M::jpos[j][0] + cc * M::jpos[j][1]);
-                    T sj, cj;
-                    t_sincos(M::dof_sgn[j] * dq, &sj, &cj);
+                    T ja, jb;
+                    t_rot(cc, ss, M::jpos[j][0], M::jpos[j][1], &ja, &jb);
+                    const T ax = px + ja, ay = py + jb;
+                    const T sj = hs[TP::T.hinge_rank[j]], cj = hc[TP::T.hinge_rank[j]];
                     const T cn = cc * cj - ss * sj, sn = ss * cj + cc * sj;
                     cc = cn; ss = sn;
-                    px = ax - (cc * M::jpos[j][0] - ss * M::jpos[j][1]);
-                    py = ay - (ss * M::jpos[j][0] + cc * M::jpos[j][1]);
+                    t_rot(cc, ss, M::jpos[j][0], M::jpos[j][1], &ja, &jb);
+                    px = ax - ja; py = ay - jb;
                     anca[k] = ax; ancb[k] = ay;
                 }
             }
@@ -394,8 +470,9 @@ struct Lean {
                 pa[b] = px; pb[b] = py;
             }
             c[b] = cc; s[b] = ss;
-            const T cwa = pa[b] + (cc * M::com[b][0] - ss * M::com[b][1]);
-            const T cwb = pb[b] + (ss * M::com[b][0] + cc * M::com[b][1]);
+            T cwa, cwb;
+            t_rot(cc, ss, M::com[b][0], M::com[b][1], &cwa, &cwb);
+            cwa = pa[b] + cwa; cwb = pb[b] + cwb;
             ha[b] = M::mass[b] * cwa; hb[b] = M::mass[b] * cwb;
             IO[b] = M::izz[b] + M::mass[b] * (cwa * cwa + cwb * cwb);
             if (M::HAS_SITE && b == M::site_body) {
@@ -476,8 +553,9 @@ struct Lean {
                     MBRL_UNROLL
                     for (int e = 0; e < 2; e++) {
                         const double la = e ? M::g_eb[g][0] : M::g_ea[g][0], lb = e ? M::g_eb[g][1] : M::g_ea[g][1];
-                        const T ea = pa[b] + (cc * la - ss * lb);   // sphere centre rel. O
-                        const T eb = pb[b] + (ss * la + cc * lb);
+                        T ea, eb;                                   // sphere centre rel. O
+                        t_rot(cc, ss, la, lb, &ea, &eb);
+                        ea = pa[b] + ea; eb = pb[b] + eb;
                         const T dist = ((Ob + eb) - M::FLOOR_Z) - M::g_rad[g];
                         if (MBRL_RARE(t_val(dist) < M::c_margin[g])) {
                             if (nslot >= K) { status |= ST_OVERFLOW; continue; }

@@ -18,9 +18,7 @@ def build(name, flags):
     import mbrl_amd
     from mbrl_amd import build as b
     os.makedirs(VDIR, exist_ok=True)
-    subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed",
-                           "-mllvm", "-pragma-unroll-threshold=1000000", "-mllvm", "-disable-machine-licm"] + flags +
-                          ["-o", os.path.join(VDIR, name + ".so"), os.path.join(b.CSRC, "mbrl_hip.hip")], cwd=b.CSRC)
+    b.compile_lib(os.path.join(VDIR, name + ".so"), flags)
 
 
 def child(path):

@@ -11,16 +11,14 @@ sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "tests", "_build", "libmbrl_phase.so")
 NAMES = {0: "sweep + smooth forces", 1: "unconstrained solve (crba, factor, solve)", 2: "newton pass (residuals, J^T f, Hessian)",
          3: "factor + solve + norms", 4: "M s for the line search", 5: "line search", 6: "solver exit", 7: "euler (crba, factor, solve, integrate)",
-         8: "loop glue", 9: "reward + exit"}
+         8: "loop glue", 9: "reward + exit", 10: "(two calibration marks)"}
 
 
 def build():
     import mbrl_amd
     from mbrl_amd import build as b
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed",
-                           "-mllvm", "-pragma-unroll-threshold=1000000", "-mllvm", "-disable-machine-licm",
-                           "-DMBRL_PHASE_TIMING", "-o", OUT, os.path.join(b.CSRC, "mbrl_hip.hip")], cwd=b.CSRC)
+    b.compile_lib(OUT, ["-DMBRL_PHASE_TIMING"])
 
 
 def main():
