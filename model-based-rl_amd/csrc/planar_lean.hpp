@@ -1087,6 +1087,7 @@ struct Lean {
             MBRL_PHASE(4);
             T alpha = T(1.0), lo = T(0.0), hi = T(-1.0);  // hi < 0: no upper bracket yet
             uint32_t llm = lm, lcm = cm;                   // active set the current alpha was derived from
+            bool exact = false;
             MBRL_NOUNROLL
             for (int ls = 0; ls < kMaxLineSearch; ls++) {
                 MBRL_LOOP_FENCE;
@@ -1094,7 +1095,7 @@ struct Lean {
                 T g = a1 + alpha * a2, h = a2;
                 uint32_t nlm, ncm;
                 line_pass(qacc, sx, alpha, g, h, nlm, ncm);
-                if (nlm == llm && ncm == lcm) break;       // alpha is the exact root of its own piece
+                if (nlm == llm && ncm == lcm) { exact = true; break; }   // alpha is the exact root of its own piece
                 llm = nlm; lcm = ncm;
                 if (t_val(g) < 0.0) lo = alpha; else hi = alpha;
                 T an = alpha - g / h;
@@ -1105,6 +1106,16 @@ struct Lean {
             MBRL_PHASE(5);
             MBRL_UNROLL
             for (int j = 0; j < NV; j++) { qacc[j] = qacc[j] + alpha * sx[j]; gs[j] = gs[j] + alpha * Ms[j]; }
+#ifndef MBRL_NO_STATIONARY_EXIT
+            // The search ended on the very active set the Hessian was built from: the new point is the Newton point
+            // of a set that reproduces itself, i.e. the solution, and stationarity there reads  J^T f = gs.
+            if (exact && llm == plm && lcm == pcm) {
+                converged = true;
+                MBRL_UNROLL
+                for (int j = 0; j < NV; j++) fcon[j] = gs[j];
+                break;
+            }
+#endif
         }
         if (!converged) status |= ST_NOCONVERGE;
     }
