@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MBRL_ABI_VERSION 1
+#define MBRL_ABI_VERSION 2
 
 /* per-unit status bits (replace mujoco-py's MujocoException / the reference's asserts,
  * backward.py:371,374) */
@@ -68,6 +68,19 @@ int mbrl_fd_jacobians(const mbrl_model *m, int64_t N, const double *qpos, const 
                       const double *ctrl, double eps, int fd_mode, int nsteps, double *dsds, double *dsda,
                       double *drds, double *drda, double *s_next, double *reward, uint32_t *status,
                       void *hip_stream);
+
+/* The same with cfg.MODEL.POLICY.NETWORK = True (mujoco/utils/backward.py:418-419, 460-461): a rollout whose
+ * qvel / qpos entry is perturbed runs under the policy's action AT the perturbed state, so the state
+ * columns become total derivatives through the policy.  The caller evaluates the policy (a GEMM-shaped
+ * batch, outside this library) and passes the actions:
+ *   ctrl_pert [N, nv+nq, nu]      forward mode; row j < nv: qvel[j] + eps, row nv+j: qpos[j] + eps
+ *   ctrl_pert [N, nv+nq, 2, nu]   central mode; [..,0,:] at +eps, [..,1,:] at -eps
+ * (backward.py's own order: velocities first, then positions).  The nominal rollout and the ctrl-perturbed
+ * rollouts use `ctrl`.  ctrl_pert == NULL is mbrl_fd_jacobians. */
+int mbrl_fd_jacobians_closed_loop(const mbrl_model *m, int64_t N, const double *qpos, const double *qvel,
+                                  const double *ctrl, const double *ctrl_pert, double eps, int fd_mode, int nsteps,
+                                  double *dsds, double *dsda, double *drds, double *drda, double *s_next,
+                                  double *reward, uint32_t *status, void *hip_stream);
 
 /* Replaces the chain of MjBlock.backward calls that autograd issues for one epoch
  * (model/blocks/mujoco.py:43-104; recurrence in SURVEY.md App. C): for each of B

@@ -207,7 +207,9 @@ class Agent:
             fd_mode = lib.FD_CENTRAL if str(cfg.MODEL.get("FD_MODE", "forward")) == "central" else lib.FD_FORWARD
             out = agent.engine.fd_jacobians(data_snapshot.qpos, data_snapshot.qvel, data_snapshot.ctrl,
                                             eps=float(cfg.MODEL.get("FD_EPS", 1e-6)), fd_mode=fd_mode,
-                                            nsteps=int(cfg.MODEL.NSTEPS_FOR_BACKWARD))
+                                            nsteps=int(cfg.MODEL.NSTEPS_FOR_BACKWARD),
+                                            # backward.py:418-419,460-461: closed-loop re-query of the policy
+                                            policy=agent.policy_net if cfg.MODEL.POLICY.NETWORK else None)
             if test and int(cfg.MODEL.NSTEPS_FOR_BACKWARD) == 1:
                 ns = torch.as_tensor(next_state, device=out["s_next"].device).reshape(out["s_next"].shape)
                 rw = torch.as_tensor(reward, device=out["reward"].device).reshape(out["reward"].shape)

@@ -77,6 +77,8 @@ _DEFAULTS = {
         "NSTEPS_FOR_BACKWARD": 1, "FRAME_SKIP": 1, "TIMESTEP": 0.0, "RANDOM_SEED": 0,
         # additions of this build (not in the reference): FD scheme selection
         "FD_EPS": 1e-6, "FD_MODE": "forward",
+        # "fused": H step launches + ONE FD launch over B*H units + one scan per epoch; "ops": the reference's op graph
+        "ENGINE_PATH": "fused",
     },
     "MUJOCO": {"ENV": "InvertedPendulumEnv", "ASSETS_PATH": "./mujoco/assets/", "REWARD_SCALE": 1,
                "CLIP_ACTIONS": True, "POOL_SIZE": {}},

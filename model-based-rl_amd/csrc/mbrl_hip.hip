@@ -66,7 +66,8 @@ template <class M, bool STEP_NAME>
 __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_skip, int nsteps, double eps, int mode,
                                                           const double *__restrict__ qpos,
                                                           const double *__restrict__ qvel,
-                                                          const double *__restrict__ ctrl, double *__restrict__ dsds,
+                                                          const double *__restrict__ ctrl,
+                                                          const double *__restrict__ ctrl_pert, double *__restrict__ dsds,
                                                           double *__restrict__ dsda, double *__restrict__ drds,
                                                           double *__restrict__ drda, double *__restrict__ s_next,
                                                           double *__restrict__ qpos_next, double *__restrict__ qvel_next,
@@ -103,6 +104,12 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_sk
         if (p > 0) {
             idx = p - 1;
             if (central) { d = (idx & 1) ? -eps : eps; idx >>= 1; }
+        }
+        // closed-loop linearisation (backward.py:418-419,460-461): a state-perturbed rollout runs under the
+        // policy's action AT the perturbed state, row (unit, column[, sign]) of ctrl_pert; columns in qvel, qpos order
+        if (ctrl_pert && idx >= NU) {
+            const int64_t col = unit * (2 * NV) + (idx - NU);
+            cp = ctrl_pert + (central ? 2 * col + (d < 0.0 ? 1 : 0) : col) * NU;
         }
 #pragma unroll
         for (int k = 0; k < NU; k++) S.mem.st(LY::OC + k, idx == k ? cp[k] + d : cp[k]);
@@ -299,7 +306,7 @@ static int check_launch(const mbrl_model *m, const char *what) {
 
 template <class M>
 static void launch_rollouts(const mbrl_model *m, int64_t N, int mode, const double *qpos, const double *qvel,
-                            const double *ctrl, double eps, int nsteps, double *dsds, double *dsda, double *drds,
+                            const double *ctrl, const double *ctrl_pert, double eps, int nsteps, double *dsds, double *dsda, double *drds,
                             double *drda, double *s_next, double *qpos_next, double *qvel_next, double *reward,
                             uint32_t *status, hipStream_t st) {
     constexpr int NP = M::NU + 2 * M::NV;
@@ -308,10 +315,12 @@ static void launch_rollouts(const mbrl_model *m, int64_t N, int mode, const doub
     const int64_t blocks = (N + upb - 1) / upb;
     if (mode == MODE_STEP)
         hipLaunchKernelGGL((rollout_kernel<M, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, N, m->frame_skip, nsteps,
-                           eps, mode, qpos, qvel, ctrl, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward, status);
+                           eps, mode, qpos, qvel, ctrl, ctrl_pert, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward,
+                           status);
     else
         hipLaunchKernelGGL((rollout_kernel<M, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, N, m->frame_skip, nsteps,
-                           eps, mode, qpos, qvel, ctrl, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward, status);
+                           eps, mode, qpos, qvel, ctrl, ctrl_pert, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward,
+                           status);
 }
 
 #ifdef MBRL_PHASE_TIMING
@@ -372,7 +381,7 @@ int mbrl_step(const mbrl_model *m, int64_t N, const double *qpos, const double *
     if (N > (int64_t(1) << 31)) return fail(-6, "mbrl_step: N too large for one launch");
     if (hipSetDevice(m->device) != hipSuccess) return fail(-4, "mbrl_step: hipSetDevice failed");
     hipStream_t st = (hipStream_t)hip_stream;
-    MBRL_DISPATCH(m->env_id, (launch_rollouts<M>(m, N, MODE_STEP, qpos, qvel, ctrl, 0.0, 1, nullptr, nullptr, nullptr,
+    MBRL_DISPATCH(m->env_id, (launch_rollouts<M>(m, N, MODE_STEP, qpos, qvel, ctrl, nullptr, 0.0, 1, nullptr, nullptr, nullptr,
                                                  nullptr, nullptr, qpos_next, qvel_next, reward, status, st)));
     return check_launch(m, "mbrl_step");
 }
@@ -380,6 +389,14 @@ int mbrl_step(const mbrl_model *m, int64_t N, const double *qpos, const double *
 int mbrl_fd_jacobians(const mbrl_model *m, int64_t N, const double *qpos, const double *qvel, const double *ctrl,
                       double eps, int fd_mode, int nsteps, double *dsds, double *dsda, double *drds, double *drda,
                       double *s_next, double *reward, uint32_t *status, void *hip_stream) {
+    return mbrl_fd_jacobians_closed_loop(m, N, qpos, qvel, ctrl, nullptr, eps, fd_mode, nsteps, dsds, dsda, drds, drda,
+                                         s_next, reward, status, hip_stream);
+}
+
+int mbrl_fd_jacobians_closed_loop(const mbrl_model *m, int64_t N, const double *qpos, const double *qvel,
+                                  const double *ctrl, const double *ctrl_pert, double eps, int fd_mode, int nsteps,
+                                  double *dsds, double *dsda, double *drds, double *drda, double *s_next,
+                                  double *reward, uint32_t *status, void *hip_stream) {
     if (!m) return fail(-1, "mbrl_fd_jacobians: null model");
     if (N < 0) return fail(-6, "mbrl_fd_jacobians: negative N");
     if (N == 0) return 0;
@@ -391,7 +408,7 @@ int mbrl_fd_jacobians(const mbrl_model *m, int64_t N, const double *qpos, const 
     if (hipSetDevice(m->device) != hipSuccess) return fail(-4, "mbrl_fd_jacobians: hipSetDevice failed");
     hipStream_t st = (hipStream_t)hip_stream;
     MBRL_DISPATCH(m->env_id, (launch_rollouts<M>(m, N, fd_mode == MBRL_FD_CENTRAL ? MODE_CENTRAL : MODE_FORWARD, qpos, qvel,
-                                                 ctrl, eps, nsteps, dsds, dsda, drds, drda, s_next, nullptr, nullptr,
+                                                 ctrl, ctrl_pert, eps, nsteps, dsds, dsda, drds, drda, s_next, nullptr, nullptr,
                                                  reward, status, st)));
     return check_launch(m, "mbrl_fd_jacobians");
 }

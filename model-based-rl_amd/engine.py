@@ -65,19 +65,48 @@ class FdEngine:
                                        _ptr(st), self._stream()))
         return qn, vn, r, st
 
-    def fd_jacobians(self, qpos, qvel, ctrl, eps=1e-6, fd_mode=lib.FD_FORWARD, nsteps=1, out=None):
+    def perturbed_policy_actions(self, qpos, qvel, policy, eps=1e-6, fd_mode=lib.FD_FORWARD):
+        """Closed-loop mode (cfg.MODEL.POLICY.NETWORK, backward.py:418-419,460-461): the policy's action at every
+        state-perturbed copy of every unit, in backward.py's order (qvel entries, then qpos entries).  The state
+        reaches the policy as float32 and the action comes back as float64, exactly as the reference casts them.
+        Returns ctrl_pert [N, nv+nq, nu] (forward) or [N, nv+nq, 2, nu] (central)."""
+        N, n, nq = qpos.shape[0], self.n, self.nq
+        s = torch.cat([qpos, qvel], dim=1)
+        col = torch.tensor([nq + j for j in range(self.nv)] + list(range(nq)), device=self.device)
+        e = torch.zeros((n, n), dtype=torch.float64, device=self.device)
+        e[torch.arange(n, device=self.device), col] = eps
+        if fd_mode == lib.FD_CENTRAL:
+            P = torch.stack([s[:, None, :] + e, s[:, None, :] - e], dim=2)      # [N, n, 2, n]
+        else:
+            P = s[:, None, :] + e                                               # [N, n, n]
+        # a strategy object offers its deterministic mean (exploration noise re-drawn per perturbed copy would
+        # swamp an eps = 1e-6 difference); a plain callable / nn.Module is used as it is
+        fn = getattr(policy, "mean_action", policy)
+        with torch.no_grad():
+            a = fn(P.reshape(-1, n).float()).double()
+        return a.reshape(P.shape[:-1] + (self.nu,)).contiguous()
+
+    def fd_jacobians(self, qpos, qvel, ctrl, eps=1e-6, fd_mode=lib.FD_FORWARD, nsteps=1, out=None, policy=None,
+                     ctrl_pert=None):
         qpos, qvel, ctrl = self._in(qpos, self.nq), self._in(qvel, self.nv), self._in(ctrl, self.nu)
         N, n, nu = qpos.shape[0], self.n, self.nu
         if qvel.shape[0] != N or ctrl.shape[0] != N:
             raise ValueError("ragged batch")
+        if policy is not None and ctrl_pert is None and N:
+            ctrl_pert = self.perturbed_policy_actions(qpos, qvel, policy, eps, fd_mode)
+        if ctrl_pert is not None:
+            want = N * n * nu * (2 if fd_mode == lib.FD_CENTRAL else 1)
+            ctrl_pert = torch.as_tensor(ctrl_pert, dtype=torch.float64, device=self.device).contiguous()
+            if ctrl_pert.numel() != want:
+                raise ValueError("ctrl_pert has %d elements, expected %d" % (ctrl_pert.numel(), want))
         o = out or dict(dsds=self._new(N, n, n), dsda=self._new(N, n, nu), drds=self._new(N, n),
                         drda=self._new(N, nu), s_next=self._new(N, n), reward=self._new(N),
                         status=self._new(N, dtype=torch.int32))
         with torch.cuda.device(self.device):
-            lib.check(self.L.mbrl_fd_jacobians(self.h, N, _ptr(qpos), _ptr(qvel), _ptr(ctrl), float(eps),
-                                               int(fd_mode), int(nsteps), _ptr(o["dsds"]), _ptr(o["dsda"]),
-                                               _ptr(o["drds"]), _ptr(o["drda"]), _ptr(o["s_next"]),
-                                               _ptr(o["reward"]), _ptr(o["status"]), self._stream()))
+            lib.check(self.L.mbrl_fd_jacobians_closed_loop(
+                self.h, N, _ptr(qpos), _ptr(qvel), _ptr(ctrl), _ptr(ctrl_pert), float(eps), int(fd_mode), int(nsteps),
+                _ptr(o["dsds"]), _ptr(o["dsda"]), _ptr(o["drds"]), _ptr(o["drda"]), _ptr(o["s_next"]),
+                _ptr(o["reward"]), _ptr(o["status"]), self._stream()))
         return o
 
     def vjp_scan(self, jac, c, grad_weights="average"):

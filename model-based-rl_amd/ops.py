@@ -46,11 +46,21 @@ def mj_torch_block_factory(agent, mode):
             else:
                 weight = 1 / (P.MAX_HORIZON_STEPS - ctx.data_snapshot.step_idx.value)
 
+            # 'prioritise': the reference visits episodes one after the other (last to first) and lets
+            # agent.running_sum carry over between them (mujoco.py:65); when B episodes advance together the sum
+            # episode b has seen is the scalar accumulated over its own steps plus what the later episodes added
+            def running_sum():
+                B, H = agent.batch, P.MAX_HORIZON_STEPS
+                if B == 1:
+                    return agent.running_sum
+                off = torch.arange(B - 1, -1, -1, dtype=torch.float64, device=grad_output.device) * (0.5 * H * (H + 1))
+                return (agent.running_sum + off).reshape(B, 1, 1)
+
             if mode == "dynamics":
                 state_jacobian = agent.dynamics_gradients["state"]
                 action_jacobian = agent.dynamics_gradients["action"]
                 if P.GRAD_WEIGHTS == "prioritise":
-                    action_jacobian = (1.0 / agent.running_sum) * action_jacobian
+                    action_jacobian = (1.0 / running_sum()) * action_jacobian
                 elif P.GRAD_WEIGHTS == "average":
                     action_jacobian = weight * action_jacobian
             elif mode == "reward":
@@ -62,7 +72,7 @@ def mj_torch_block_factory(agent, mode):
                 action_jacobian = agent.reward_gradients["action"]
                 if P.GRAD_WEIGHTS == "prioritise":
                     state_jacobian = (weight - 1) * state_jacobian
-                    action_jacobian = (weight / agent.running_sum) * action_jacobian
+                    action_jacobian = (weight / running_sum()) * action_jacobian
                 elif P.GRAD_WEIGHTS == "average":
                     action_jacobian = weight * action_jacobian
             else:

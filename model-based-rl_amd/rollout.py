@@ -36,3 +36,56 @@ def action_gradients(engine, states, actions, c, grad_weights="average", eps=1e-
     jac = engine.fd_jacobians(s[:, :nq], s[:, nq:], actions.reshape(B * H, nu), eps=eps, fd_mode=fd_mode)
     da, ds0 = engine.vjp_scan(jac, c, grad_weights)
     return da, ds0, jac
+
+
+class RolloutRewards(torch.autograd.Function):
+    """rewards [B, H] of a stored rollout as a differentiable function of (actions [B, H, nu], s0 [B, n]).
+
+    Forward hands back the rewards the step kernel produced; backward is the whole chain of MjBlock.backward
+    calls autograd would issue for the epoch (model/blocks/mujoco.py:43-104) in two launches: ONE FD launch over
+    the B*H stored (s_t, a_t) and one scan.  Closed-loop mode passes `policy` (cfg.MODEL.POLICY.NETWORK,
+    backward.py:418-419,460-461).  `grad_weights` is cfg.MODEL.POLICY.GRAD_WEIGHTS."""
+
+    @staticmethod
+    def forward(ctx, actions, s0, engine, states, rewards, grad_weights, eps, fd_mode, policy, raise_on_status):
+        ctx.engine, ctx.gw, ctx.eps, ctx.fd_mode, ctx.policy, ctx.chk = engine, grad_weights, eps, fd_mode, policy, raise_on_status
+        ctx.save_for_backward(actions.detach(), states)
+        # the reference's reward op rounds through fp32 (torch.Tensor([r]).double(), mujoco.py:38); kept
+        return rewards.float().double()
+
+    @staticmethod
+    def backward(ctx, c):
+        actions, states = ctx.saved_tensors
+        eng = ctx.engine
+        B, H, nu = actions.shape
+        s = states[:, :H].reshape(B * H, eng.n)
+        jac = eng.fd_jacobians(s[:, :eng.nq], s[:, eng.nq:], actions.reshape(B * H, nu), eps=ctx.eps, fd_mode=ctx.fd_mode,
+                               policy=ctx.policy)
+        if ctx.chk and int((jac["status"] != 0).sum()):
+            raise lib.MbrlError("FD linearisation flagged %d of %d units (status bits, include/mbrl.h)"
+                                % (int((jac["status"] != 0).sum()), B * H))
+        da, ds0 = eng.vjp_scan(jac, c.contiguous(), ctx.gw)
+        return da, ds0, None, None, None, None, None, None, None, None
+
+
+def rollout_with_policy(engine, agent, model_policy, s0, horizon):
+    """Forward pass of one epoch for all episodes together (trainer.py:57-74 + basic.py:29-46): the policy sees
+    the DETACHED state (basic.py:38), the step kernel advances every episode.  Returns states [B, H+1, n],
+    actions [B, H, nu] (with their autograd graph to the policy parameters), rewards [B, H], status [B, H]."""
+    B = s0.shape[0]
+    nq = engine.nq
+    states = torch.empty((B, horizon + 1, engine.n), dtype=torch.float64, device=engine.device)
+    rewards = torch.empty((B, horizon), dtype=torch.float64, device=engine.device)
+    status = torch.empty((B, horizon), dtype=torch.int32, device=engine.device)
+    states[:, 0] = s0
+    acts = []
+    for t in range(horizon):
+        agent.set_step_idx(t)
+        s = states[:, t]
+        a = model_policy(s.detach().float()).double()
+        acts.append(a)
+        qn, vn, r, st = engine.step(s[:, :nq], s[:, nq:], a.detach())
+        states[:, t + 1, :nq], states[:, t + 1, nq:] = qn, vn
+        rewards[:, t], status[:, t] = r, st
+    agent.set_step_idx(horizon)
+    return states, torch.stack(acts, dim=1), rewards, status

@@ -169,7 +169,71 @@ def run(env, weights, nsteps, H, seed, B=2):
     print("wrote", os.path.basename(path), "calls", len(rec), "|grad|", float(np.abs(out["grad_actions"]).max()))
 
 
+def mlp_from_arrays(w0, b0, w1, b1):
+    """The closed-loop policy of the fixture: Linear -> LeakyReLU -> Linear in float32 (the shape of the
+    reference's FeedForward mean network, model/layers/feed_forward.py:25-62)."""
+    net = torch.nn.Sequential(torch.nn.Linear(w0.shape[1], w0.shape[0]), torch.nn.LeakyReLU(),
+                              torch.nn.Linear(w1.shape[1], w1.shape[0]))
+    with torch.no_grad():
+        net[0].weight.copy_(torch.from_numpy(w0)); net[0].bias.copy_(torch.from_numpy(b0))
+        net[2].weight.copy_(torch.from_numpy(w1)); net[2].bias.copy_(torch.from_numpy(b1))
+    return net
+
+
+def run_closed_loop(env, seed, K=6, hidden=16):
+    """cfg.MODEL.POLICY.NETWORK = True: calculate_gradients re-queries agent.policy_net on every state-perturbed
+    copy (backward.py:418-419,460-461).  K on-trajectory snapshots, Jacobians as the reference computes them."""
+    rng = np.random.default_rng(seed)
+    agent = FakeAgent(env, 40, "average", 1)
+    agent.cfg.MODEL.POLICY.NETWORK = True
+    o = agent.o
+    w0 = (0.3 * rng.standard_normal((hidden, o.n))).astype(np.float32); b0 = (0.1 * rng.standard_normal(hidden)).astype(np.float32)
+    w1 = (0.3 * rng.standard_normal((o.nu, hidden))).astype(np.float32); b1 = (0.1 * rng.standard_normal(o.nu)).astype(np.float32)
+    agent.policy_net = mlp_from_arrays(w0, b0, w1, b1)
+    q = rng.uniform(-0.05, 0.05, o.nq); v = 0.1 * rng.standard_normal(o.nv)
+    if env in ("HopperEnv", "Walker2dEnv"):
+        q[1] += 1.25; q[3:] = -np.abs(q[3:])
+    n, nu = o.n, o.nu
+    out = dict(env=env, w0=w0, b0=b0, w1=w1, b1=b1, qpos=np.zeros((K, o.nq)), qvel=np.zeros((K, o.nv)), ctrl=np.zeros((K, nu)),
+               dsds=np.zeros((K, n, n)), dsda=np.zeros((K, n, nu)), drds=np.zeros((K, n)), drda=np.zeros((K, nu)),
+               s_next=np.zeros((K, n)), reward=np.zeros(K), ctrl_pert=np.zeros((K, n, nu)))
+    net, log = agent.policy_net, []
+
+    def recording_policy(x):     # the actions the reference's FD loop obtained, in its own order (qvel, then qpos)
+        y = net(x)
+        log.append(y.double().detach().numpy().copy())
+        return y
+    agent.data.qpos[:] = q; agent.data.qvel[:] = v
+    for k in range(K):
+        for _ in range(3):      # advance a few env steps under the policy between snapshots
+            a = agent.policy_net(torch.from_numpy(np.concatenate((agent.data.qpos, agent.data.qvel))).float()).double().detach().numpy()
+            agent.step(np.clip(a, -1, 1))
+        a = agent.policy_net(torch.from_numpy(np.concatenate((agent.data.qpos, agent.data.qvel))).float()).double().detach().numpy()
+        agent.data.ctrl[:] = a
+        snap = agent.get_snapshot()
+        ns, r, _, _ = agent.step(agent.data.ctrl.copy())
+        del log[:]
+        agent.policy_net = recording_policy
+        ref_backward.calculate_gradients(agent, snap, ns, r, test=True)
+        agent.policy_net = net
+        assert len(log) == n
+        out["ctrl_pert"][k] = np.stack(log)
+        out["qpos"][k], out["qvel"][k], out["ctrl"][k] = snap.qpos, snap.qvel, snap.ctrl
+        out["dsds"][k], out["dsda"][k] = agent.dynamics_gradients["state"], agent.dynamics_gradients["action"]
+        out["drds"][k], out["drda"][k] = agent.reward_gradients["state"][0], agent.reward_gradients["action"][0]
+        out["s_next"][k], out["reward"][k] = ns, r
+        agent.set_snapshot(snap)
+        agent.step(np.clip(snap.ctrl, -1, 1))
+    path = os.path.join(HERE, "refcl_%s.npz" % env)
+    np.savez_compressed(path, **out)
+    print("wrote", os.path.basename(path), "|A|", float(np.abs(out["dsds"]).max()))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "closed_loop":
+        for env in ("HalfCheetahEnv", "SwimmerEnv", "InvertedDoublePendulumEnv"):
+            run_closed_loop(env, seed=21)
+        sys.exit(0)
     H = 5
     for env in ("InvertedPendulumEnv", "InvertedDoublePendulumEnv", "SwimmerEnv", "HopperEnv", "Walker2dEnv",
                 "HalfCheetahEnv"):

@@ -61,3 +61,40 @@ def test_recurrence_reproduces_reference_autograd(path):
     da, ds0 = recurrence(g, str(g["weights"]))
     np.testing.assert_allclose(da, g["grad_actions"], rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(ds0, g["grad_s0"], rtol=1e-10, atol=1e-12)
+
+
+GOLD_CL = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "refcl_*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLD_CL, ids=[os.path.basename(p)[6:-4] for p in GOLD_CL])
+def test_oracle_closed_loop_fd_reproduces_reference(path):
+    """cfg.MODEL.POLICY.NETWORK = True (backward.py:418-419,460-461): state-perturbed rollouts run under the policy's
+    action at the perturbed state.  Oracle steps + the fixture's policy, assembled as calculate_gradients does."""
+    import util
+    g = np.load(path)
+    o = Oracle(str(g["env"]))
+    q, v, c = g["qpos"], g["qvel"], g["ctrl"]
+    K, nq, nv, nu, n = q.shape[0], o.nq, o.nv, o.nu, o.n
+    cp = g["ctrl_pert"]
+    assert np.abs(util.closed_loop_actions_cpu(g) - cp).max() < 1e-5
+    eps = 1e-6
+    qn, vn, r, st = o.step(q, v, c)
+    assert (st == 0).all()
+    assert np.array_equal(np.concatenate([qn, vn], 1), g["s_next"]) and np.array_equal(r, g["reward"])
+    for k in range(K):
+        A = np.zeros((n, n)); rs = np.zeros(n)
+        for j in range(nv + nq):
+            qq, vv = q[k].copy(), v[k].copy()
+            if j < nv:
+                vv[j] += eps
+            else:
+                qq[j - nv] += eps
+            q1, v1, r1, _ = o.step(qq, vv, cp[k, j])
+            col = nq + j if j < nv else j - nv
+            A[:nq, col] = (q1[0] - qn[k]) / eps
+            A[nq:, col] = (v1[0] - vn[k]) / eps
+            rs[col] = (r1[0] - r[k]) / eps
+        assert np.array_equal(A, g["dsds"][k]) and np.array_equal(rs, g["drds"][k])
+    # the ctrl columns are the open-loop ones
+    ol = o.fd_jacobians(q, v, c)
+    assert np.array_equal(ol["dsda"], g["dsda"]) and np.array_equal(ol["drda"], g["drda"])
