@@ -41,7 +41,7 @@ __device__ __forceinline__ void mbrl_phase_mark(int k, unsigned long long &last)
 namespace mbrl {
 
 #ifndef MBRL_BLOCK
-#define MBRL_BLOCK 128
+#define MBRL_BLOCK 64
 #endif
 constexpr int kBlock = MBRL_BLOCK;
 
@@ -60,6 +60,46 @@ __device__ unsigned long long *g_wave_timing = nullptr;
 // the same machine code and agree bit for bit (the reference asserts exactly that, backward.py:371,374).
 //   mode FORWARD: R = 1 + NP rollouts per unit (NP = nu + nv + nq), CENTRAL: R = 1 + 2 NP, STEP: R = 1.
 // Column order of calculate_gradients: ctrl, then qvel, then qpos (backward.py:389,409,433).
+//
+// Workgroup = ONE wave.  Waves that share a workgroup wait for each other at the end (their LDS is released
+// together) and the rollouts of different units take different numbers of solver iterations, so a workgroup of
+// 2 (4) waves idled 8 % (12 %) of its time; single-wave workgroups finish independently, four resident per CU.
+// To keep the lanes full although R does not divide 64, two consecutive waves (a "pair") share one unit: wave 0
+// runs its nominal rollout and the first perturbations, wave 1 runs the nominal rollout AGAIN (1 lane) and the
+// remaining perturbations; each wave differences against its own copy of the nominal (the two copies execute the
+// same instructions on the same inputs), so the waves never exchange data.  HalfCheetah, forward mode: 5 units
+// per pair, 126 of 128 lanes busy.
+struct WaveMap {
+    int R, A, L, nsp, A1, upp;   // rollouts/unit; full units in wave 0; lanes of the shared unit in wave 0 (0: none);
+                                 // its perturbations in wave 1; full units in wave 1; units per pair
+    __host__ __device__ WaveMap(int R_, bool central) : R(R_) {
+        A = 64 / R;
+        L = 64 - A * R;
+        if (central && L > 0 && ((L - 1) & 1)) L -= 1;   // a +eps / -eps couple stays in one wave
+        if (L < (central ? 3 : 2) || R == 1) L = 0;
+        if (L) { nsp = R - L; A1 = (64 - 1 - nsp) / R; upp = A + 1 + A1; }
+        else { nsp = 0; A1 = A; upp = 2 * A; }
+    }
+    // lane t of wave `half` -> unit u of the pair, rollout p of that unit, lane of the nominal it differences against
+    __device__ bool lane(int half, int t, int &u, int &p, int &nom, bool &primary) const {
+        primary = true;
+        if (half == 0) {
+            if (t < A * R) { u = t / R; p = t - u * R; nom = u * R; return true; }
+            if (t < A * R + L) { u = A; p = t - A * R; nom = A * R; return true; }
+            return false;
+        }
+        if (L) {
+            if (t <= nsp) { u = A; p = t ? L + t - 1 : 0; nom = 0; primary = false; return true; }
+            const int k = (t - 1 - nsp) / R;
+            u = A + 1 + k; p = (t - 1 - nsp) - k * R; nom = 1 + nsp + k * R;
+            return k < A1;
+        }
+        const int k = t / R;
+        u = A + k; p = t - k * R; nom = k * R;
+        return k < A1;
+    }
+};
+
 // STEP_NAME only gives plain-step launches their own symbol in profiler output (the body does not use it,
 // so both instantiations are compiled from identical IR; tests/test_gpu_parity.py checks the bits).
 template <class M, bool STEP_NAME>
@@ -74,42 +114,39 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_sk
                                                           double *__restrict__ reward, uint32_t *__restrict__ status) {
     using LY = Layout<M>;
     constexpr int NV = M::NV, NU = M::NU, NS = 2 * NV, ROW = NS + 1, NP = NU + 2 * NV;
-    static_assert(LY::NMEM >= ROW, "the staging buffer re-uses the lane columns");
-    static_assert(1 + 2 * NP <= kBlock, "a unit's rollouts must fit one workgroup");
-    __shared__ double lds[LY::NMEM * kBlock];   // lane columns during the rollouts, then res[UPB*R][ROW]
-    __shared__ unsigned stat[kBlock];
-    double *res = lds;
+    static_assert(kBlock == 64, "one wave per workgroup");
+    static_assert(1 + 2 * NP <= kBlock, "a unit's rollouts must fit one wave");
+    __shared__ double lds[LY::NMEM * kBlock];   // lane columns
 
     const bool central = mode == MODE_CENTRAL;
-    const int R = mode == MODE_STEP ? 1 : (central ? 1 + 2 * NP : 1 + NP);   // rollouts per unit
-    const int UPB = kBlock / R;                                              // units per workgroup
+    const WaveMap wm(mode == MODE_STEP ? 1 : (central ? 1 + 2 * NP : 1 + NP), central);
     const int t = threadIdx.x;
-    const int u = t / R, p = t - u * R;
-    const int64_t unit0 = int64_t(blockIdx.x) * UPB;
-    const int64_t unit = unit0 + u;
-    stat[t] = 0;
-    __syncthreads();
+    int u, p, nom;
+    bool primary;
+    const bool mapped = wm.lane(int(blockIdx.x & 1u), t, u, p, nom, primary);
+    const int64_t unit = int64_t(blockIdx.x >> 1) * wm.upp + u;
     MBRL_STAMP(0);
 
-    const bool live = u < UPB && unit < N;
+    const bool live = mapped && unit < N;
     double o[ROW];
     unsigned st = 0;
+    int idx = -1;            // perturbed input (ctrl, qvel, qpos order), -1: nominal
+    bool minus = false;      // the -eps member of a central couple
     if (live) {
         Lean<M, double, LaneMem<double, kBlock>> S;
         S.status = 0;
         S.mem.p = lds + t;
         const double *qp = qpos + unit * NV, *vp = qvel + unit * NV, *cp = ctrl + unit * NU;
-        int idx = -1;
         double d = eps;
         if (p > 0) {
             idx = p - 1;
-            if (central) { d = (idx & 1) ? -eps : eps; idx >>= 1; }
+            if (central) { minus = idx & 1; d = minus ? -eps : eps; idx >>= 1; }
         }
         // closed-loop linearisation (backward.py:418-419,460-461): a state-perturbed rollout runs under the
         // policy's action AT the perturbed state, row (unit, column[, sign]) of ctrl_pert; columns in qvel, qpos order
         if (ctrl_pert && idx >= NU) {
             const int64_t col = unit * (2 * NV) + (idx - NU);
-            cp = ctrl_pert + (central ? 2 * col + (d < 0.0 ? 1 : 0) : col) * NU;
+            cp = ctrl_pert + (central ? 2 * col + (minus ? 1 : 0) : col) * NU;
         }
 #pragma unroll
         for (int k = 0; k < NU; k++) S.mem.st(LY::OC + k, idx == k ? cp[k] + d : cp[k]);
@@ -141,79 +178,47 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_sk
         for (int j = 0; j < NV; j++) { o[j] = S.mem.ld(LY::OQ + j); o[NV + j] = S.mem.ld(LY::OV + j); }
         o[NS] = r;
         st = S.status;
+    } else {
+#pragma unroll
+        for (int j = 0; j < ROW; j++) o[j] = 0.0;
     }
     MBRL_STAMP(1);
-    __syncthreads();                      // every lane is done with its column: re-use LDS as res
     MBRL_STAMP(2);
-    if (live) {
-        double *ro = res + (u * R + p) * ROW;
-#pragma unroll
-        for (int j = 0; j < ROW; j++) ro[j] = o[j];
-        if (st) atomicOr(&stat[u], st);
-    }
-    __syncthreads();
 
-    int64_t nun = N - unit0;
-    if (nun > UPB) nun = UPB;
-    const int nu_blk = int(nun);
+    // ---- Jacobian columns: every perturbed lane differences its own result against the reference lane of its
+    // unit in THIS wave (forward: the nominal; central: its -eps partner, the next lane) and writes its column.
+    // Lanes of one unit hold consecutive columns, so the stores of a wave fall in runs of nu / nv / nq doubles.
     const double den = central ? 2.0 * eps : eps;
-    // perturbation slot of input column `in` (0..NP-1 in ctrl,qvel,qpos order)
-    auto plus = [central](int in) { return central ? 1 + 2 * in : 1 + in; };
-    auto minus = [central](int in) { return central ? 2 + 2 * in : 0; };
-
-    if (dsds) {  // [unit][o][col], col < NV: qpos input, else qvel input
-        double *base = dsds + unit0 * NS * NS;
-        for (int e = t; e < nu_blk * NS * NS; e += kBlock) {
-            const int uu = e / (NS * NS), rem = e - uu * NS * NS, o = rem / NS, col = rem - o * NS;
-            const int in = col < NV ? NU + NV + col : NU + (col - NV);
-            const double *ru = res + uu * R * ROW;
-            base[e] = (ru[plus(in) * ROW + o] - ru[minus(in) * ROW + o]) / den;
+    const int ref = central ? (t + 1) & 63 : nom;
+    const bool writes = live && p > 0 && !minus;
+    const int col = idx < NU ? idx : (idx < NU + NV ? NV + (idx - NU) : idx - NU - NV);   // column in its output array
+    double *js = nullptr, *jr = nullptr;     // this lane's column of the state / reward Jacobian
+    int stride = 0;
+    if (writes) {
+        if (idx < NU) { if (dsda) js = dsda + unit * (NS * NU) + col; if (drda) jr = drda + unit * NU + col; stride = NU; }
+        else { if (dsds) js = dsds + unit * (NS * NS) + col; if (drds) jr = drds + unit * NS + col; stride = NS; }
+    }
+#pragma unroll
+    for (int j = 0; j < ROW; j++) {
+        const double base = __shfl(o[j], ref, 64);
+        const double dv = (o[j] - base) / den;
+        if (j < NS) { if (js) js[j * stride] = dv; }
+        else if (jr) *jr = dv;
+    }
+    // ---- the nominal rollout (the wave that owns the unit's first lanes writes it) ----
+    if (live && p == 0 && primary) {
+        if (s_next) {
+#pragma unroll
+            for (int j = 0; j < NS; j++) s_next[unit * NS + j] = o[j];
         }
-    }
-    if (dsda) {
-        double *base = dsda + unit0 * NS * NU;
-        for (int e = t; e < nu_blk * NS * NU; e += kBlock) {
-            const int uu = e / (NS * NU), rem = e - uu * NS * NU, o = rem / NU, k = rem - o * NU;
-            const double *ru = res + uu * R * ROW;
-            base[e] = (ru[plus(k) * ROW + o] - ru[minus(k) * ROW + o]) / den;
+        if (qpos_next) {
+#pragma unroll
+            for (int j = 0; j < NV; j++) { qpos_next[unit * NV + j] = o[j]; qvel_next[unit * NV + j] = o[NV + j]; }
         }
+        if (reward) reward[unit] = o[NS];
     }
-    if (drds) {
-        double *base = drds + unit0 * NS;
-        for (int e = t; e < nu_blk * NS; e += kBlock) {
-            const int uu = e / NS, col = e - uu * NS;
-            const int in = col < NV ? NU + NV + col : NU + (col - NV);
-            const double *ru = res + uu * R * ROW;
-            base[e] = (ru[plus(in) * ROW + NS] - ru[minus(in) * ROW + NS]) / den;
-        }
-    }
-    if (drda) {
-        double *base = drda + unit0 * NU;
-        for (int e = t; e < nu_blk * NU; e += kBlock) {
-            const int uu = e / NU, k = e - uu * NU;
-            const double *ru = res + uu * R * ROW;
-            base[e] = (ru[plus(k) * ROW + NS] - ru[minus(k) * ROW + NS]) / den;
-        }
-    }
-    if (s_next) {
-        double *base = s_next + unit0 * NS;
-        for (int e = t; e < nu_blk * NS; e += kBlock) {
-            const int uu = e / NS, o = e - uu * NS;
-            base[e] = res[uu * R * ROW + o];
-        }
-    }
-    if (qpos_next) {   // split form of s_next (mbrl_step)
-        double *bq = qpos_next + unit0 * NV, *bv = qvel_next + unit0 * NV;
-        for (int e = t; e < nu_blk * NV; e += kBlock) {
-            const int uu = e / NV, o = e - uu * NV;
-            bq[e] = res[uu * R * ROW + o];
-            bv[e] = res[uu * R * ROW + NV + o];
-        }
-    }
-    if (t < nu_blk) {
-        if (reward) reward[unit0 + t] = res[t * R * ROW + NS];
-        if (status) status[unit0 + t] = stat[t];
-    }
+    // status: OR over the unit's rollouts; a unit can live in two waves, so it is accumulated in HBM (zeroed by the host)
+    if (status && live && st) atomicOr(&status[unit], st);
     MBRL_STAMP(3);
 }
 
@@ -305,14 +310,16 @@ static int check_launch(const mbrl_model *m, const char *what) {
 }
 
 template <class M>
-static void launch_rollouts(const mbrl_model *m, int64_t N, int mode, const double *qpos, const double *qvel,
-                            const double *ctrl, const double *ctrl_pert, double eps, int nsteps, double *dsds, double *dsda, double *drds,
-                            double *drda, double *s_next, double *qpos_next, double *qvel_next, double *reward,
-                            uint32_t *status, hipStream_t st) {
+static int launch_rollouts(const mbrl_model *m, int64_t N, int mode, const double *qpos, const double *qvel,
+                           const double *ctrl, const double *ctrl_pert, double eps, int nsteps, double *dsds, double *dsda,
+                           double *drds, double *drda, double *s_next, double *qpos_next, double *qvel_next, double *reward,
+                           uint32_t *status, hipStream_t st) {
     constexpr int NP = M::NU + 2 * M::NV;
-    const int R = mode == MODE_STEP ? 1 : (mode == MODE_CENTRAL ? 1 + 2 * NP : 1 + NP);
-    const int upb = kBlock / R;
-    const int64_t blocks = (N + upb - 1) / upb;
+    const bool central = mode == MODE_CENTRAL;
+    const WaveMap wm(mode == MODE_STEP ? 1 : (central ? 1 + 2 * NP : 1 + NP), central);
+    const int64_t blocks = 2 * ((N + wm.upp - 1) / wm.upp);
+    // per-unit status words are OR-ed into HBM by the waves (a unit can span two): start from zero, in stream order
+    if (status && hipMemsetAsync(status, 0, sizeof(uint32_t) * size_t(N), st) != hipSuccess) return -1;
     if (mode == MODE_STEP)
         hipLaunchKernelGGL((rollout_kernel<M, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, N, m->frame_skip, nsteps,
                            eps, mode, qpos, qvel, ctrl, ctrl_pert, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward,
@@ -321,6 +328,7 @@ static void launch_rollouts(const mbrl_model *m, int64_t N, int mode, const doub
         hipLaunchKernelGGL((rollout_kernel<M, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, N, m->frame_skip, nsteps,
                            eps, mode, qpos, qvel, ctrl, ctrl_pert, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward,
                            status);
+    return 0;
 }
 
 #ifdef MBRL_PHASE_TIMING
@@ -381,8 +389,10 @@ int mbrl_step(const mbrl_model *m, int64_t N, const double *qpos, const double *
     if (N > (int64_t(1) << 31)) return fail(-6, "mbrl_step: N too large for one launch");
     if (hipSetDevice(m->device) != hipSuccess) return fail(-4, "mbrl_step: hipSetDevice failed");
     hipStream_t st = (hipStream_t)hip_stream;
-    MBRL_DISPATCH(m->env_id, (launch_rollouts<M>(m, N, MODE_STEP, qpos, qvel, ctrl, nullptr, 0.0, 1, nullptr, nullptr, nullptr,
-                                                 nullptr, nullptr, qpos_next, qvel_next, reward, status, st)));
+    int rc = 0;
+    MBRL_DISPATCH(m->env_id, (rc = launch_rollouts<M>(m, N, MODE_STEP, qpos, qvel, ctrl, nullptr, 0.0, 1, nullptr, nullptr,
+                                                      nullptr, nullptr, nullptr, qpos_next, qvel_next, reward, status, st)));
+    if (rc) return fail(-10, "mbrl_step: clearing the status words failed");
     return check_launch(m, "mbrl_step");
 }
 
@@ -407,9 +417,11 @@ int mbrl_fd_jacobians_closed_loop(const mbrl_model *m, int64_t N, const double *
     if (N > (int64_t(1) << 31)) return fail(-6, "mbrl_fd_jacobians: N too large for one launch");
     if (hipSetDevice(m->device) != hipSuccess) return fail(-4, "mbrl_fd_jacobians: hipSetDevice failed");
     hipStream_t st = (hipStream_t)hip_stream;
-    MBRL_DISPATCH(m->env_id, (launch_rollouts<M>(m, N, fd_mode == MBRL_FD_CENTRAL ? MODE_CENTRAL : MODE_FORWARD, qpos, qvel,
-                                                 ctrl, ctrl_pert, eps, nsteps, dsds, dsda, drds, drda, s_next, nullptr, nullptr,
-                                                 reward, status, st)));
+    int rc = 0;
+    MBRL_DISPATCH(m->env_id, (rc = launch_rollouts<M>(m, N, fd_mode == MBRL_FD_CENTRAL ? MODE_CENTRAL : MODE_FORWARD, qpos,
+                                                      qvel, ctrl, ctrl_pert, eps, nsteps, dsds, dsda, drds, drda, s_next,
+                                                      nullptr, nullptr, reward, status, st)));
+    if (rc) return fail(-10, "mbrl_fd_jacobians: clearing the status words failed");
     return check_launch(m, "mbrl_fd_jacobians");
 }
 

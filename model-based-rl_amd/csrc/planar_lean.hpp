@@ -808,9 +808,10 @@ struct Lean {
                 MBRL_UNROLL
                 for (int g = M::NGEOM - 1; g >= 0; g--) {
                     if (M::g_body[g] != b || !M::c_on[g]) continue;
+                    if (!MBRL_RARE(cand_on & (3u << TP::T.cand_rank[g][0]))) continue;   // neither end of this capsule
                     MBRL_UNROLL
                     for (int e = 1; e >= 0; e--) {
-                        if (MBRL_RARE(cand_on & (1u << TP::T.cand_rank[g][e]))) {
+                        if (cand_on & (1u << TP::T.cand_rank[g][e])) {
                             const T Pa = cs.cur[0], Pb = cs.cur[1], D = cs.cur[2], arn = cs.cur[3], art = cs.cur[4];
                             const int sh = csh;
                             csh -= 3;
@@ -923,16 +924,18 @@ struct Lean {
         Pop<LY::OL, 2> ls;
         if (M::HAS_FLOOR) cs.start(mem, nslot);
         if (LY::NLIM > 0) ls.start(mem, nlimrow);
-        MBRL_UNROLL
-        for (int j = NV - 1; j >= 0; j--) {
-            if (!M::limited[j]) continue;
-            if (MBRL_RARE(lim_on & (1u << j))) {
-                const T D = ls.cur[0], aref = ls.cur[1];
-                ls.next(mem);
-                const bool up = (lim_hi >> j) & 1u;
-                const T jar = (up ? -x[j] : x[j]) - aref, jv = up ? -sx[j] : sx[j];
-                const T r = jar + alpha * jv;
-                if (t_val(r) < 0.0) { lm |= 1u << j; g = g + D * r * jv; h = h + D * jv * jv; }
+        if (MBRL_RARE(lim_on != 0)) {     // one test for all limit rows: active joint limits are rare
+            MBRL_UNROLL
+            for (int j = NV - 1; j >= 0; j--) {
+                if (!M::limited[j]) continue;
+                if (lim_on & (1u << j)) {
+                    const T D = ls.cur[0], aref = ls.cur[1];
+                    ls.next(mem);
+                    const bool up = (lim_hi >> j) & 1u;
+                    const T jar = (up ? -x[j] : x[j]) - aref, jv = up ? -sx[j] : sx[j];
+                    const T r = jar + alpha * jv;
+                    if (t_val(r) < 0.0) { lm |= 1u << j; g = g + D * r * jv; h = h + D * jv * jv; }
+                }
             }
         }
         MBRL_UNROLL
@@ -948,15 +951,16 @@ struct Lean {
                 if (t_val(r) < 0.0) { lm |= 1u << (NV + k); g = g + D * r * jv; h = h + D * jv * jv; }
             }
         }
-        if (!M::HAS_FLOOR) return;
+        if (!M::HAS_FLOOR || cand_on == 0) return;
         int csh = 3 * (nslot - 1);
         MBRL_UNROLL
         for (int gi = M::NGEOM - 1; gi >= 0; gi--) {
             if (!M::c_on[gi]) continue;
+            if (!MBRL_RARE(cand_on & (3u << TP::T.cand_rank[gi][0]))) continue;   // neither end of this capsule
             const int b = M::g_body[gi];
             MBRL_UNROLL
             for (int e = 1; e >= 0; e--) {
-                if (MBRL_RARE(cand_on & (1u << TP::T.cand_rank[gi][e]))) {
+                if (cand_on & (1u << TP::T.cand_rank[gi][e])) {
                     const T Pa = cs.cur[0], Pb = cs.cur[1], D = cs.cur[2], arn = cs.cur[3], art = cs.cur[4];
                     const int sh = csh;
                     csh -= 3;

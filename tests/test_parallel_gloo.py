@@ -82,3 +82,35 @@ def test_two_rank_gradient_allreduce_matches_single_process(tmp_path):
     ref, B = _grads(0, 6)
     assert got["n"][0] == B and got["tmax"] == 2.0
     np.testing.assert_allclose(got["g"], ref, rtol=1e-12, atol=1e-14)
+
+
+def _strategy_worker(rank, world, port, out):
+    """Sharded optimisation step of the in-repo strategy: each rank owns a block of episodes, weights its loss by
+    local_batch / BATCH_SIZE, and the gradients meet in ONE flattened all-reduce (trainer.do_training's grad_sync)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import mbrl_amd
+    from mbrl_amd import parallel
+    from test_strategy_host import strategy_step
+    lo, hi = parallel.shard_range(6, rank, world)
+    params = strategy_step((lo, hi), grad_sync=parallel.allreduce_sum_)
+    if rank == 0:
+        np.savez(out, **{k: v.numpy() for k, v in params.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_strategy_step_matches_single_process(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_strategy_host import strategy_step
+    out = str(tmp_path / "s0.npz")
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_strategy_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    ref = strategy_step((0, 6), grad_sync=None)
+    for k, v in ref.items():
+        np.testing.assert_allclose(got[k], v.numpy(), rtol=1e-12, atol=1e-14)

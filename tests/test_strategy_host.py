@@ -133,3 +133,20 @@ def test_build_policy_names():
     cfg.MODEL.POLICY.ARCH = "Nope"
     with pytest.raises(AttributeError):
         build_policy(cfg, fake_agent())
+
+
+def strategy_step(shard, grad_sync):
+    """One optimisation step of VariationalOptimization on episodes [lo, hi) of a fixed synthetic batch of 6; returns
+    the parameters after the step (used by the gloo world-size-2 test as well)."""
+    cfg = cfg_vo(B=6, H=4)
+    np.random.seed(1)
+    pol = VariationalOptimization(cfg, fake_agent(batch=shard[1] - shard[0]), shard=shard)
+    w = torch.tensor(np.random.default_rng(5).standard_normal((6, 4)))
+    rows = slice(shard[0], shard[1])
+    out = []
+    for t in range(4):
+        pol.step_idx.set(t)
+        act = pol(torch.zeros(shard[1] - shard[0], 4))
+        out.append((act ** 2).sum(dim=1) * w[rows, t])
+    pol.optimize(torch.stack(out, dim=1), grad_sync=grad_sync)
+    return {k: v.detach().clone() for k, v in pol.state_dict().items()}
