@@ -33,7 +33,7 @@ def main():
     lib._lib = None
     lib.LIB_PATH = OUT
     eng = FdEngine("HalfCheetahEnv")
-    upb = int(os.environ.get("UPB", 5)); wpb = int(os.environ.get("WPB", 2)); nblk = (N + upb - 1) // upb
+    upb = int(os.environ.get("UPB", 5)); wpb = 1; nblk = 2 * ((N + upb - 1) // upb)
     buf = torch.zeros((nblk * wpb, 4), dtype=torch.int64, device="cuda")
     assert eng.L.mbrl_debug_set_wave_timing(C.c_void_p(buf.data_ptr())) == 0
     out = eng.fd_jacobians(q, v, c)
