@@ -77,6 +77,13 @@ constexpr double kMinVal = 1e-15;
 constexpr unsigned ST_NONFINITE = 1u, ST_NOCONVERGE = 2u, ST_OVERFLOW = 4u, ST_DEGENERATE = 8u;
 constexpr int kMaxNewton = 100;
 constexpr int kMaxLineSearch = 40;
+// The first Newton iterations take the full step without a line search (measured on on-trajectory HalfCheetah
+// states, per wave and mj_step: 1.9 passes + 3.0 line evaluations with the search from the start, 2.7 + 0.2 with
+// two full steps first).  The minimum is unique and every exit tests the active set, so the path does not matter.
+#ifndef MBRL_UNIT_ITERS
+#define MBRL_UNIT_ITERS 2
+#endif
+constexpr int kUnitIters = MBRL_UNIT_ITERS;
 
 // ---- scalar helpers (overloaded by the host-side counting type) ----
 MBRL_HD double t_abs(double x) { return fabs(x); }
@@ -1089,6 +1096,11 @@ struct Lean {
             for (int j = 0; j < NV; j++) a2 = a2 + sx[j] * Ms[j];
             MBRL_PIN(Ms, NV);
             MBRL_PHASE(4);
+            if (it < kUnitIters) {
+                MBRL_UNROLL
+                for (int j = 0; j < NV; j++) { qacc[j] = qacc[j] + sx[j]; gs[j] = gs[j] + Ms[j]; }
+                continue;
+            }
             T alpha = T(1.0), lo = T(0.0), hi = T(-1.0);  // hi < 0: no upper bracket yet
             uint32_t llm = lm, lcm = cm;                   // active set the current alpha was derived from
             bool exact = false;
