@@ -1,10 +1,11 @@
 """GPU parity tests proper: HIP path (through the C ABI) vs the CPU oracle on identical inputs.
 
-Tolerances (fp64): s' and reward <= 1e-9 abs-rel; FD Jacobians <= 2e-6 relative to the largest
-entry (one-sided differences with eps = 1e-6 amplify the ~1e-15 step-level disagreement between two
-different arithmetic formulations -- 3-D oracle vs planar kernel -- by 1/eps; units whose active
-constraint set flips inside a perturbation are compared column-wise with the same bound since both
-sides see the same flip)."""
+Tolerances (fp64): s' <= 1e-11, reward <= 1e-10 abs-rel; FD Jacobians <= 5e-7 relative to the unit's
+largest entry (one-sided differences with eps = 1e-6 amplify the ~1e-15..1e-13 step-level disagreement
+between two different arithmetic formulations -- 3-D oracle with exact line search vs planar kernel with its
+own solver schedule -- by 1/eps; units whose active constraint set flips inside a perturbation are compared
+column-wise with the same bound since both sides see the same flip).  Measured margins (tools/parity_margins.py):
+worst Jacobian entry 1.5e-7 (HalfCheetah dsda), 1e-8 or better elsewhere; s' 1.5e-13 or better."""
 import numpy as np
 import pytest
 
@@ -37,9 +38,9 @@ def test_step_matches_oracle(env, torch_cuda):
     assert (st.cpu().numpy() == so.astype(np.int32)).all()
     ok = so == 0          # units whose physics is well defined (no crossing capsule axes, solver converged)
     assert ok.mean() > 0.8
-    assert util.relerr(qn.cpu().numpy()[ok], qo[ok]) < 1e-9
-    assert util.relerr(vn.cpu().numpy()[ok], vo[ok]) < 1e-8
-    assert util.relerr(r.cpu().numpy()[ok], ro[ok]) < 1e-8
+    assert util.relerr(qn.cpu().numpy()[ok], qo[ok]) < 1e-11
+    assert util.relerr(vn.cpu().numpy()[ok], vo[ok]) < 1e-10
+    assert util.relerr(r.cpu().numpy()[ok], ro[ok]) < 1e-10
 
 
 @pytest.mark.parametrize("fd_mode", [0, 1])
@@ -58,14 +59,14 @@ def test_fd_jacobians_match_oracle(env, fd_mode, torch_cuda):
     got = {k: a[ok] for k, a in got.items()}
     ref = {k: a[ok] for k, a in ref.items()}
     q = q[ok]
-    assert util.relerr(got["s_next"], ref["s_next"]) < 1e-9
-    assert util.relerr(got["reward"], ref["reward"]) < 1e-8
+    assert util.relerr(got["s_next"], ref["s_next"]) < 1e-11
+    assert util.relerr(got["reward"], ref["reward"]) < 1e-10
     for k in ("dsds", "dsda", "drds", "drda"):
         # per-unit scale: largest |entry| of that unit's Jacobian
         a, b = got[k].reshape(len(q), -1), ref[k].reshape(len(q), -1)
         scale = 1.0 + np.abs(b).max(axis=1, keepdims=True)
         err = np.abs(a - b) / scale
-        assert err.max() < 2e-6, (k, float(err.max()), int(err.max(axis=1).argmax()))
+        assert err.max() < 5e-7, (k, float(err.max()), int(err.max(axis=1).argmax()))
 
 
 @pytest.mark.parametrize("env", util.ENVS)
