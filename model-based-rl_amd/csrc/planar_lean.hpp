@@ -93,8 +93,14 @@ MBRL_HD double t_sqrt(double x) { return sqrt(x); }
 MBRL_HD double t_pow(double x, double y) { return pow(x, y); }
 MBRL_HD double t_fmod(double x, double y) { return fmod(x, y); }
 MBRL_HD double t_cos(double x) { return cos(x); }
-MBRL_HD bool t_finite(double x) {   // exponent test on the bits: survives no-NaN / no-infinity compilation
-    return ((__builtin_bit_cast(uint64_t, x) >> 52) & 0x7ffu) != 0x7ffu;
+MBRL_HD bool t_finite(double x) {
+    // Exponent test on the high word, made opaque as an INTEGER: under no-NaN / no-infinity compilation the
+    // optimiser recognises the plain bit test as a floating-point class test and folds it to true.
+    uint32_t hi = uint32_t(__builtin_bit_cast(uint64_t, x) >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(hi));
+#endif
+    return (hi & 0x7ff00000u) != 0x7ff00000u;
 }
 MBRL_HD double t_val(double x) { return x; }
 MBRL_HD double t_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
