@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Report how far the HIP path is from the oracle (same measure as tests/test_gpu_parity.py) -- margins, not a test."""
+"""Checker script (not collected by pytest; lives under tests/ because it uses the oracle).
+Report how far the HIP path is from the oracle (same measure as tests/test_gpu_parity.py) -- margins, not a test."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ -> repo root
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import numpy as np

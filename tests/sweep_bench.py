@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Measurement sweep of SURVEY.md 8(d), on the GPU box: every env, forward (reference parity) and central
+"""Measurement script (not collected by pytest; lives under tests/ because its CPU-baseline leg uses the oracle).
+Measurement sweep of SURVEY.md 8(d), on the GPU box: every env, forward (reference parity) and central
 differences, N = 2^10 .. 2^18 for the headline env, counted flops per unit, share of constrained units, and the CPU
 oracle on 1 thread / 16 threads.  Writes a markdown report (default gpurun_out/sweep.md)."""
 import ctypes as C
@@ -7,7 +8,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ -> repo root
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import numpy as np

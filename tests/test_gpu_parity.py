@@ -4,7 +4,7 @@ Tolerances (fp64): s' <= 1e-11, reward <= 1e-10 abs-rel; FD Jacobians <= 5e-7 re
 largest entry (one-sided differences with eps = 1e-6 amplify the ~1e-15..1e-13 step-level disagreement
 between two different arithmetic formulations -- 3-D oracle with exact line search vs planar kernel with its
 own solver schedule -- by 1/eps; units whose active constraint set flips inside a perturbation are compared
-column-wise with the same bound since both sides see the same flip).  Measured margins (tools/parity_margins.py):
+column-wise with the same bound since both sides see the same flip).  Measured margins (tests/parity_margins.py):
 worst Jacobian entry 1.5e-7 (HalfCheetah dsda), 1e-8 or better elsewhere; s' 1.5e-13 or better."""
 import numpy as np
 import pytest
