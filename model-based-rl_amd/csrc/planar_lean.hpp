@@ -144,13 +144,27 @@ MBRL_HD void t_sincos(T x, T *s, T *c) {
 
 // sin and cos of N angles at once, coefficient by coefficient: the twelve polynomial constants are then
 // materialised once per batch instead of once per angle (they are scalar-register literals on the device).
+#define MBRL_SINCOS_TABLE                                                                                        \
+    {1.58969099521155010221e-10, -2.50507602534068634195e-08, 2.75573137070700676789e-06, -1.98412698298579493134e-04, \
+     8.33333333332248946124e-03, -1.66666666666666324348e-01, -1.13596475577881948265e-11, 2.08757232129817482790e-09, \
+     -2.75573143513906633035e-07, 2.48015872894767294178e-05, -1.38888888888741095749e-03, 4.16666666666666019037e-02}
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MBRL_LITERAL_SINCOS)
+// On the device the twelve coefficients come from constant memory: two scalar loads per sweep put them in scalar
+// registers, where every Horner step reads them as an operand; as literals each use cost two vector moves (the fmac
+// form wants the addend in its destination).  Not `const`, so the optimiser cannot fold them back into literals.
+// (The same for the whole model-constant table was measured and rejected: the loads are hoisted to the top of the
+// sweep and the scalar registers spill into vector lanes.)
+__constant__ double mbrl_sincos_tab[12] = MBRL_SINCOS_TABLE;
+#define MBRL_SC(i) mbrl_sincos_tab[i]
+#else
+constexpr double mbrl_sincos_tab_host[12] = MBRL_SINCOS_TABLE;
+#define MBRL_SC(i) mbrl_sincos_tab_host[i]
+#endif
 template <class T, int N>
 MBRL_HD void t_sincos_batch(const T *x, T *s, T *c) {
     static_assert(N >= 1, "");
-    constexpr double SC[6] = {1.58969099521155010221e-10, -2.50507602534068634195e-08, 2.75573137070700676789e-06,
-                              -1.98412698298579493134e-04, 8.33333333332248946124e-03, -1.66666666666666324348e-01};
-    constexpr double CC[6] = {-1.13596475577881948265e-11, 2.08757232129817482790e-09, -2.75573143513906633035e-07,
-                              2.48015872894767294178e-05, -1.38888888888741095749e-03, 4.16666666666666019037e-02};
+    const double SC[6] = {MBRL_SC(0), MBRL_SC(1), MBRL_SC(2), MBRL_SC(3), MBRL_SC(4), MBRL_SC(5)};
+    const double CC[6] = {MBRL_SC(6), MBRL_SC(7), MBRL_SC(8), MBRL_SC(9), MBRL_SC(10), MBRL_SC(11)};
     T k[N], r[N], z[N], ps[N], pc[N];
     MBRL_UNROLL
     for (int i = 0; i < N; i++) k[i] = t_rint(x[i] * T(6.36619772367581382433e-01));
