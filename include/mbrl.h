@@ -94,6 +94,16 @@ int mbrl_vjp_scan(const mbrl_model *m, int64_t B, int H, int grad_weights, const
                   const double *dsda, const double *drds, const double *drda, const double *c, double *da,
                   double *ds0, void *hip_stream);
 
+/* Introspection (host only, no GPU call; no counterpart in the reference): how the rollouts of a launch are laid
+ * out over the 2 x 64 lanes of a wave pair for a model with the given dimensions.  fd_mode: MBRL_FD_FORWARD, MBRL_FD_CENTRAL, or -1 for
+ * mbrl_step.  For lane i of the pair (i < 64: first wave): unit[i] = unit index within the pair (-1: idle lane),
+ * rollout[i] = 0 for the nominal rollout, k >= 1 for the k-th perturbed one (forward: input k-1 in ctrl, qvel, qpos
+ * order; central: input (k-1)/2, +eps for odd k, -eps for even k), ref_lane[i] = lane (within the same wave) of the
+ * nominal rollout it is differenced against, primary[i] = 1 if this wave writes the unit's nominal outputs.
+ * All four arrays have 128 entries. */
+int mbrl_lane_map(int nq, int nv, int nu, int fd_mode, int *units_per_pair, int *unit, int *rollout, int *ref_lane,
+                  int *primary);
+
 const char *mbrl_last_error(void);
 
 #ifdef __cplusplus

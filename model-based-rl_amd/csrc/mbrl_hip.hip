@@ -81,7 +81,7 @@ struct WaveMap {
         else { nsp = 0; A1 = A; upp = 2 * A; }
     }
     // lane t of wave `half` -> unit u of the pair, rollout p of that unit, lane of the nominal it differences against
-    __device__ bool lane(int half, int t, int &u, int &p, int &nom, bool &primary) const {
+    __host__ __device__ bool lane(int half, int t, int &u, int &p, int &nom, bool &primary) const {
         primary = true;
         if (half == 0) {
             if (t < A * R) { u = t / R; p = t - u * R; nom = u * R; return true; }
@@ -348,6 +348,26 @@ extern "C" int mbrl_debug_set_wave_timing(void *buf) {
 extern "C" {
 
 int mbrl_abi_version(void) { return MBRL_ABI_VERSION; }
+
+int mbrl_lane_map(int nq, int nv, int nu, int fd_mode, int *units_per_pair, int *unit, int *rollout, int *ref_lane,
+                  int *primary) {
+    if (!unit || !rollout || !ref_lane || !primary) return fail(-1, "mbrl_lane_map: null argument");
+    if (fd_mode < -1 || fd_mode > MBRL_FD_CENTRAL) return fail(-7, "mbrl_lane_map: bad fd_mode");
+    const int NP = nu + nq + nv;
+    if (nq < 1 || nv < 1 || nu < 0 || 1 + 2 * NP > 64) return fail(-6, "mbrl_lane_map: a unit's rollouts must fit one wave");
+    const bool central = fd_mode == MBRL_FD_CENTRAL;
+    const WaveMap wm(fd_mode < 0 ? 1 : (central ? 1 + 2 * NP : 1 + NP), central);
+    if (units_per_pair) *units_per_pair = wm.upp;
+    for (int half = 0; half < 2; half++)
+        for (int t = 0; t < 64; t++) {
+            int u = -1, p = -1, nom = -1;
+            bool prim = false;
+            const bool ok = wm.lane(half, t, u, p, nom, prim);
+            const int i = half * 64 + t;
+            unit[i] = ok ? u : -1; rollout[i] = ok ? p : -1; ref_lane[i] = ok ? nom : -1; primary[i] = ok && prim;
+        }
+    return 0;
+}
 
 const char *mbrl_last_error(void) { return g_err; }
 

@@ -13,7 +13,7 @@ ST_NONFINITE, ST_NOCONVERGE, ST_OVERFLOW, ST_DEGENERATE = 1, 2, 4, 8
 FD_FORWARD, FD_CENTRAL = 0, 1
 
 SYMBOLS = ("mbrl_abi_version", "mbrl_model_create", "mbrl_model_destroy", "mbrl_model_dims", "mbrl_step",
-           "mbrl_fd_jacobians", "mbrl_fd_jacobians_closed_loop", "mbrl_vjp_scan", "mbrl_last_error")
+           "mbrl_fd_jacobians", "mbrl_fd_jacobians_closed_loop", "mbrl_vjp_scan", "mbrl_lane_map", "mbrl_last_error")
 
 _lib = None
 vp = C.c_void_p

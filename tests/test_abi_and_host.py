@@ -83,3 +83,46 @@ def test_index_is_shared_by_reference():
     assert alias == 1 and snap == 0 and int(i - snap) == 1
     i.set(snap)
     assert alias == 0
+
+
+@pytest.mark.parametrize("dims", [(2, 2, 1), (3, 3, 1), (5, 5, 2), (6, 6, 3), (9, 9, 6)])
+@pytest.mark.parametrize("fd_mode", [-1, 0, 1])
+def test_lane_map_covers_every_rollout_once(dims, fd_mode):
+    """Host logic of the launch layout: over the 128 lanes of a wave pair every rollout of every unit
+    appears exactly once (the nominal of a unit shared by the two waves: once per wave, one of them primary), every
+    perturbed lane has its nominal -- and, for central differences, its -eps partner -- in its OWN wave."""
+    import mbrl_amd
+    from mbrl_amd import lib
+    L = lib.load()
+    nq, nv, nu = dims
+    NP = nu + nq + nv
+    R = 1 if fd_mode < 0 else (1 + 2 * NP if fd_mode == 1 else 1 + NP)
+    arr = lambda: (C.c_int * 128)()
+    upp, unit, roll, ref, prim = C.c_int(), arr(), arr(), arr(), arr()
+    assert L.mbrl_lane_map(nq, nv, nu, fd_mode, C.byref(upp), unit, roll, ref, prim) == 0
+    unit, roll, ref, prim = (list(a) for a in (unit, roll, ref, prim))
+    assert upp.value >= 2 * (64 // R) and upp.value * R <= 127 + (1 if 64 % R == 0 else 0)
+    seen = {}
+    for i in range(128):
+        if unit[i] < 0:
+            continue
+        w = i // 64
+        assert 0 <= unit[i] < upp.value and 0 <= roll[i] < R
+        # reference lane: same wave, same unit, nominal rollout
+        j = w * 64 + ref[i]
+        assert unit[j] == unit[i] and roll[j] == 0
+        if fd_mode == 1 and roll[i] > 0 and roll[i] % 2 == 1:      # +eps lane: its -eps partner is the next lane
+            assert i % 64 < 63 and unit[i + 1] == unit[i] and roll[i + 1] == roll[i] + 1
+        seen.setdefault((unit[i], roll[i]), []).append((w, prim[i]))
+    for u in range(upp.value):
+        for p in range(R):
+            hits = seen.get((u, p), [])
+            if p == 0:
+                assert sum(pr for _, pr in hits) == 1 and 1 <= len(hits) <= 2      # exactly one wave writes s', r
+                assert len({w for w, _ in hits}) == len(hits)
+            else:
+                assert len(hits) == 1, (u, p, hits)
+    busy = sum(1 for x in unit if x >= 0)
+    if dims == (9, 9, 6) and fd_mode == 0:
+        assert upp.value == 5 and busy == 126
+    assert L.mbrl_lane_map(30, 30, 6, 0, None, unit_arr := arr(), arr(), arr(), arr()) == -6
