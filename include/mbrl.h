@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MBRL_ABI_VERSION 2
+#define MBRL_ABI_VERSION 3
 
 /* per-unit status bits (replace mujoco-py's MujocoException / the reference's asserts,
  * backward.py:371,374) */
@@ -81,6 +81,29 @@ int mbrl_fd_jacobians_closed_loop(const mbrl_model *m, int64_t N, const double *
                                   const double *ctrl, const double *ctrl_pert, double eps, int fd_mode, int nsteps,
                                   double *dsds, double *dsda, double *drds, double *drda, double *s_next,
                                   double *reward, uint32_t *status, void *hip_stream);
+
+/* The same linearisation in two launches, as the reference splits it: the forward op runs the nominal step
+ * (model/blocks/mujoco.py:20-31 -> mujoco/utils/forward.py:13-38) and calculate_gradients receives its next_state and
+ * reward as arguments (mujoco/utils/backward.py:343) before it runs the perturbed copies (backward.py:376-470).
+ *   mbrl_fd_plan               runs the N nominal rollouts (one lane each), keeps their results in `plan`, and sorts the
+ *                              units by the control-flow signature of their rollout (contact solver passes per
+ *                              mj_step), so that the lanes of a wave of the second launch take the same branches;
+ *                              s_next [N,n], reward [N] (either may be NULL) and status [N] are written here.
+ *   mbrl_fd_jacobians_planned  runs the perturbed rollouts only, in the planned order with every lane busy, differences
+ *                              them against the nominal results held in `plan`, writes dsds / dsda / drds / drda (as
+ *                              mbrl_fd_jacobians_closed_loop; ctrl_pert may be NULL) and ORs the perturbed rollouts'
+ *                              status bits into status [N] (pass the array mbrl_fd_plan wrote, or NULL).
+ * Both take the same N, qpos, qvel, ctrl, nsteps and the same stream (or streams ordered by the caller).  `plan` is
+ * caller-owned device memory, 256-byte aligned, of at least mbrl_fd_plan_bytes(m, N) bytes (< 0: error); the library
+ * allocates nothing.  A plan can be re-used for several mbrl_fd_jacobians_planned calls on the same inputs (forward and
+ * central, open and closed loop).  Results are those of mbrl_fd_jacobians_closed_loop bit for bit. */
+int64_t mbrl_fd_plan_bytes(const mbrl_model *m, int64_t N);
+int mbrl_fd_plan(const mbrl_model *m, int64_t N, const double *qpos, const double *qvel, const double *ctrl, int nsteps,
+                 void *plan, int64_t plan_bytes, double *s_next, double *reward, uint32_t *status, void *hip_stream);
+int mbrl_fd_jacobians_planned(const mbrl_model *m, int64_t N, const double *qpos, const double *qvel, const double *ctrl,
+                              const double *ctrl_pert, double eps, int fd_mode, int nsteps, const void *plan,
+                              int64_t plan_bytes, double *dsds, double *dsda, double *drds, double *drda,
+                              uint32_t *status, void *hip_stream);
 
 /* Replaces the chain of MjBlock.backward calls that autograd issues for one epoch
  * (model/blocks/mujoco.py:43-104; recurrence in SURVEY.md App. C): for each of B

@@ -36,6 +36,8 @@ __device__ __forceinline__ void mbrl_phase_mark(int k, unsigned long long &last)
 #define MBRL_PHASE_MEMBER unsigned long long mbrl_phase_last;
 #endif
 
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "planar_lean.hpp"
 
 namespace mbrl {
@@ -111,7 +113,12 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_sk
                                                           double *__restrict__ dsda, double *__restrict__ drds,
                                                           double *__restrict__ drda, double *__restrict__ s_next,
                                                           double *__restrict__ qpos_next, double *__restrict__ qvel_next,
-                                                          double *__restrict__ reward, uint32_t *__restrict__ status) {
+                                                          double *__restrict__ reward, uint32_t *__restrict__ status,
+                                                          const uint32_t *__restrict__ perm,
+                                                          const double *__restrict__ nom_s,
+                                                          const double *__restrict__ nom_r,
+                                                          uint32_t *__restrict__ plan_key,
+                                                          uint32_t *__restrict__ plan_idx) {
     using LY = Layout<M>;
     constexpr int NV = M::NV, NU = M::NU, NS = 2 * NV, ROW = NS + 1, NP = NU + 2 * NV;
     static_assert(kBlock == 64, "one wave per workgroup");
@@ -122,12 +129,24 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_sk
     const WaveMap wm(mode == MODE_STEP ? 1 : (central ? 1 + 2 * NP : 1 + NP), central);
     const int t = threadIdx.x;
     int u, p, nom;
-    bool primary;
-    const bool mapped = wm.lane(int(blockIdx.x & 1u), t, u, p, nom, primary);
-    const int64_t unit = int64_t(blockIdx.x >> 1) * wm.upp + u;
+    bool primary, live;
+    int64_t unit;
+    if (perm) {
+        // planned launch (mbrl_fd_jacobians_planned): perturbed rollouts only, units in the planner's order, every
+        // lane busy; the nominal results come from the plan (nom_s, nom_r).  2 NP is even, so a central couple
+        // (+eps on the even lane, -eps on the next) never straddles two waves.
+        const int64_t g = int64_t(blockIdx.x) * kBlock + t;
+        const int64_t slot = central ? g / (2 * NP) : g / NP;
+        p = 1 + int(g - slot * (central ? 2 * NP : NP));
+        live = slot < N;
+        unit = live ? int64_t(perm[slot]) : 0;
+        nom = 0; primary = true;
+    } else {
+        const bool mapped = wm.lane(int(blockIdx.x & 1u), t, u, p, nom, primary);
+        unit = int64_t(blockIdx.x >> 1) * wm.upp + u;
+        live = mapped && unit < N;
+    }
     MBRL_STAMP(0);
-
-    const bool live = mapped && unit < N;
     double o[ROW];
     unsigned st = 0;
     int idx = -1;            // perturbed input (ctrl, qvel, qpos order), -1: nominal
@@ -135,6 +154,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_sk
     if (live) {
         Lean<M, double, LaneMem<double, kBlock>> S;
         S.status = 0;
+        S.key = 0;
         S.mem.p = lds + t;
         const double *qp = qpos + unit * NV, *vp = qvel + unit * NV, *cp = ctrl + unit * NU;
         double d = eps;
@@ -178,6 +198,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_sk
         for (int j = 0; j < NV; j++) { o[j] = S.mem.ld(LY::OQ + j); o[NV + j] = S.mem.ld(LY::OV + j); }
         o[NS] = r;
         st = S.status;
+        if (plan_key) { plan_key[unit] = S.key; plan_idx[unit] = uint32_t(unit); }
     } else {
 #pragma unroll
         for (int j = 0; j < ROW; j++) o[j] = 0.0;
@@ -200,7 +221,8 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_sk
     }
 #pragma unroll
     for (int j = 0; j < ROW; j++) {
-        const double base = __shfl(o[j], ref, 64);
+        double base = __shfl(o[j], ref, 64);
+        if (perm && !central) base = j < NS ? nom_s[unit * NS + j] : nom_r[unit];
         const double dv = (o[j] - base) / den;
         if (j < NS) { if (js) js[j * stride] = dv; }
         else if (jr) *jr = dv;
@@ -313,22 +335,51 @@ template <class M>
 static int launch_rollouts(const mbrl_model *m, int64_t N, int mode, const double *qpos, const double *qvel,
                            const double *ctrl, const double *ctrl_pert, double eps, int nsteps, double *dsds, double *dsda,
                            double *drds, double *drda, double *s_next, double *qpos_next, double *qvel_next, double *reward,
-                           uint32_t *status, hipStream_t st) {
+                           uint32_t *status, hipStream_t st, const uint32_t *perm = nullptr, const double *nom_s = nullptr,
+                           const double *nom_r = nullptr, uint32_t *plan_key = nullptr, uint32_t *plan_idx = nullptr) {
     constexpr int NP = M::NU + 2 * M::NV;
     const bool central = mode == MODE_CENTRAL;
     const WaveMap wm(mode == MODE_STEP ? 1 : (central ? 1 + 2 * NP : 1 + NP), central);
-    const int64_t blocks = 2 * ((N + wm.upp - 1) / wm.upp);
+    int64_t blocks = 2 * ((N + wm.upp - 1) / wm.upp);
+    if (perm) blocks = (N * (central ? 2 * NP : NP) + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffLL) return -2;
     // per-unit status words are OR-ed into HBM by the waves (a unit can span two): start from zero, in stream order
-    if (status && hipMemsetAsync(status, 0, sizeof(uint32_t) * size_t(N), st) != hipSuccess) return -1;
+    // (a planned launch ORs into the words its plan launch wrote)
+    if (status && !perm && hipMemsetAsync(status, 0, sizeof(uint32_t) * size_t(N), st) != hipSuccess) return -1;
     if (mode == MODE_STEP)
         hipLaunchKernelGGL((rollout_kernel<M, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, N, m->frame_skip, nsteps,
                            eps, mode, qpos, qvel, ctrl, ctrl_pert, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward,
-                           status);
+                           status, perm, nom_s, nom_r, plan_key, plan_idx);
     else
         hipLaunchKernelGGL((rollout_kernel<M, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, N, m->frame_skip, nsteps,
                            eps, mode, qpos, qvel, ctrl, ctrl_pert, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward,
-                           status);
+                           status, perm, nom_s, nom_r, plan_key, plan_idx);
     return 0;
+}
+
+// ---- launch plan (mbrl_fd_plan): the nominal rollouts, their control-flow keys and the sorted unit order ----
+// Segments of the caller's plan buffer, each 256-byte aligned:
+//   key_in u32[N] | idx_in u32[N] | key_out u32[N] | perm u32[N] | nom_s f64[N * ns] | nom_r f64[N] | radix-sort scratch
+constexpr int kKeyBits = 30;   // 3 bits x the last 10 mj_forward calls (Lean::key)
+struct PlanLayout {
+    size_t key_in, idx_in, key_out, perm, nom_s, nom_r, sort_tmp, sort_bytes, total;
+};
+static bool plan_layout(int64_t N, int ns, hipStream_t st, PlanLayout &L) {
+    auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
+    size_t o = 0;
+    L.key_in = o; o = up(o + sizeof(uint32_t) * size_t(N));
+    L.idx_in = o; o = up(o + sizeof(uint32_t) * size_t(N));
+    L.key_out = o; o = up(o + sizeof(uint32_t) * size_t(N));
+    L.perm = o; o = up(o + sizeof(uint32_t) * size_t(N));
+    L.nom_s = o; o = up(o + sizeof(double) * size_t(N) * size_t(ns));
+    L.nom_r = o; o = up(o + sizeof(double) * size_t(N));
+    L.sort_tmp = o;
+    L.sort_bytes = 0;
+    uint32_t *nil = nullptr;
+    if (rocprim::radix_sort_pairs(nullptr, L.sort_bytes, nil, nil, nil, nil, size_t(N), 0, kKeyBits, st) != hipSuccess)
+        return false;
+    L.total = up(o + L.sort_bytes);
+    return true;
 }
 
 #ifdef MBRL_PHASE_TIMING
@@ -443,6 +494,82 @@ int mbrl_fd_jacobians_closed_loop(const mbrl_model *m, int64_t N, const double *
                                                       nullptr, nullptr, reward, status, st)));
     if (rc) return fail(-10, "mbrl_fd_jacobians: clearing the status words failed");
     return check_launch(m, "mbrl_fd_jacobians");
+}
+
+int64_t mbrl_fd_plan_bytes(const mbrl_model *m, int64_t N) {
+    if (!m) return fail(-1, "mbrl_fd_plan_bytes: null model");
+    if (N < 0 || N > (int64_t(1) << 31)) return fail(-6, "mbrl_fd_plan_bytes: bad N");
+    if (N == 0) return 0;
+    if (hipSetDevice(m->device) != hipSuccess) return fail(-4, "mbrl_fd_plan_bytes: hipSetDevice failed");
+    PlanLayout L;
+    if (!plan_layout(N, m->nq + m->nv, nullptr, L)) return fail(-10, "mbrl_fd_plan_bytes: sort size query failed");
+    return int64_t(L.total);
+}
+
+int mbrl_fd_plan(const mbrl_model *m, int64_t N, const double *qpos, const double *qvel, const double *ctrl, int nsteps,
+                 void *plan, int64_t plan_bytes, double *s_next, double *reward, uint32_t *status, void *hip_stream) {
+    if (!m) return fail(-1, "mbrl_fd_plan: null model");
+    if (N < 0) return fail(-6, "mbrl_fd_plan: negative N");
+    if (N == 0) return 0;
+    if (!qpos || !qvel || !ctrl || !plan) return fail(-1, "mbrl_fd_plan: null buffer");
+    if (nsteps <= 0) nsteps = 1;
+    if (N > (int64_t(1) << 31)) return fail(-6, "mbrl_fd_plan: N too large for one launch");
+    if (reinterpret_cast<uintptr_t>(plan) & 255) return fail(-7, "mbrl_fd_plan: the plan buffer must be 256-byte aligned");
+    if (hipSetDevice(m->device) != hipSuccess) return fail(-4, "mbrl_fd_plan: hipSetDevice failed");
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int ns = m->nq + m->nv;
+    PlanLayout L;
+    if (!plan_layout(N, ns, st, L)) return fail(-10, "mbrl_fd_plan: sort size query failed");
+    if (plan_bytes < int64_t(L.total))
+        return fail(-8, "mbrl_fd_plan: plan buffer too small%s (need %lld bytes, see mbrl_fd_plan_bytes)", "", (long long)L.total);
+    char *w = static_cast<char *>(plan);
+    uint32_t *key_in = reinterpret_cast<uint32_t *>(w + L.key_in), *idx_in = reinterpret_cast<uint32_t *>(w + L.idx_in);
+    uint32_t *key_out = reinterpret_cast<uint32_t *>(w + L.key_out), *perm = reinterpret_cast<uint32_t *>(w + L.perm);
+    double *nom_s = reinterpret_cast<double *>(w + L.nom_s), *nom_r = reinterpret_cast<double *>(w + L.nom_r);
+    int rc = 0;
+    MBRL_DISPATCH(m->env_id, (rc = launch_rollouts<M>(m, N, MODE_STEP, qpos, qvel, ctrl, nullptr, 0.0, nsteps, nullptr, nullptr,
+                                                      nullptr, nullptr, nom_s, nullptr, nullptr, nom_r, status, st, nullptr,
+                                                      nullptr, nullptr, key_in, idx_in)));
+    if (rc) return fail(-10, "mbrl_fd_plan: clearing the status words failed");
+    if ((rc = check_launch(m, "mbrl_fd_plan"))) return rc;
+    size_t tmp = L.sort_bytes;
+    if (rocprim::radix_sort_pairs(w + L.sort_tmp, tmp, key_in, key_out, idx_in, perm, size_t(N), 0, kKeyBits, st) != hipSuccess)
+        return fail(-10, "mbrl_fd_plan: sorting the units failed");
+    if (s_next && hipMemcpyAsync(s_next, nom_s, sizeof(double) * size_t(N) * ns, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return fail(-10, "mbrl_fd_plan: copying next_state failed");
+    if (reward && hipMemcpyAsync(reward, nom_r, sizeof(double) * size_t(N), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return fail(-10, "mbrl_fd_plan: copying reward failed");
+    return 0;
+}
+
+int mbrl_fd_jacobians_planned(const mbrl_model *m, int64_t N, const double *qpos, const double *qvel, const double *ctrl,
+                              const double *ctrl_pert, double eps, int fd_mode, int nsteps, const void *plan,
+                              int64_t plan_bytes, double *dsds, double *dsda, double *drds, double *drda, uint32_t *status,
+                              void *hip_stream) {
+    if (!m) return fail(-1, "mbrl_fd_jacobians_planned: null model");
+    if (N < 0) return fail(-6, "mbrl_fd_jacobians_planned: negative N");
+    if (N == 0) return 0;
+    if (!qpos || !qvel || !ctrl || !plan) return fail(-1, "mbrl_fd_jacobians_planned: null input buffer");
+    if (!(eps > 0)) return fail(-7, "mbrl_fd_jacobians_planned: eps must be > 0");
+    if (fd_mode != MBRL_FD_FORWARD && fd_mode != MBRL_FD_CENTRAL) return fail(-7, "mbrl_fd_jacobians_planned: bad fd_mode");
+    if (nsteps <= 0) nsteps = 1;
+    if (N > (int64_t(1) << 31)) return fail(-6, "mbrl_fd_jacobians_planned: N too large for one launch");
+    if (reinterpret_cast<uintptr_t>(plan) & 255) return fail(-7, "mbrl_fd_jacobians_planned: the plan buffer must be 256-byte aligned");
+    if (hipSetDevice(m->device) != hipSuccess) return fail(-4, "mbrl_fd_jacobians_planned: hipSetDevice failed");
+    hipStream_t st = (hipStream_t)hip_stream;
+    PlanLayout L;
+    if (!plan_layout(N, m->nq + m->nv, st, L)) return fail(-10, "mbrl_fd_jacobians_planned: sort size query failed");
+    if (plan_bytes < int64_t(L.total)) return fail(-8, "mbrl_fd_jacobians_planned: plan buffer too small");
+    const char *w = static_cast<const char *>(plan);
+    int rc = 0;
+    MBRL_DISPATCH(m->env_id,
+                  (rc = launch_rollouts<M>(m, N, fd_mode == MBRL_FD_CENTRAL ? MODE_CENTRAL : MODE_FORWARD, qpos, qvel, ctrl,
+                                           ctrl_pert, eps, nsteps, dsds, dsda, drds, drda, nullptr, nullptr, nullptr, nullptr,
+                                           status, st, reinterpret_cast<const uint32_t *>(w + L.perm),
+                                           reinterpret_cast<const double *>(w + L.nom_s),
+                                           reinterpret_cast<const double *>(w + L.nom_r))));
+    if (rc) return fail(-6, "mbrl_fd_jacobians_planned: N too large for one launch");
+    return check_launch(m, "mbrl_fd_jacobians_planned");
 }
 
 int mbrl_vjp_scan(const mbrl_model *m, int64_t B, int H, int grad_weights, const double *dsds, const double *dsda,

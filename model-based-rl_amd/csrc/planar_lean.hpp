@@ -320,6 +320,7 @@ struct Lean {
     uint32_t pair_on;
     unsigned status;
     int newton_iters;
+    uint32_t key;            // see forward(); the caller zeroes it
     MBRL_PHASE_MEMBER
 
     // ------------------------------------------------------------------ motion subspace
@@ -1074,6 +1075,7 @@ struct Lean {
             T H[NV][NV], jtf[NV], sx[NV];
             uint32_t lm, cm;
             MBRL_PHASE(8);
+            newton_iters = it + 1;
             newton_pass<true>(qacc, H, jtf, lm, cm);
             MBRL_PIN(jtf, NV);
             MBRL_UNROLL
@@ -1090,7 +1092,6 @@ struct Lean {
                 break;
             }
             plm = lm; pcm = cm;
-            newton_iters = it + 1;
             const bool ok = factor(H);
             if (!ok) { status |= ST_NONFINITE; break; }
             MBRL_UNROLL
@@ -1184,6 +1185,9 @@ struct Lean {
         for (int j = 0; j < NV; j++) fcon[j] = T(0.0);
         newton_iters = 0;
         if (constrained) solve_constraints();
+        // control-flow signature of the rollout: 3 bits per mj_forward (Hessian passes, 0 = unconstrained), latest in the
+        // low bits.  Units with equal signatures take the same branches; the launch planner sorts by it (mbrl_fd_plan).
+        key = (key << 3) | uint32_t(newton_iters < 7 ? newton_iters : 7);
         MBRL_PIN(qacc, NV); MBRL_PIN(fcon, NV);
         MBRL_PHASE(6);
     }

@@ -31,6 +31,7 @@ class FdEngine:
         lib.check(self.L.mbrl_model_dims(h, nq, nv, nu, dt))
         self.env, self.nq, self.nv, self.nu, self.dt = env, nq.value, nv.value, nu.value, dt.value
         self.n = self.nq + self.nv
+        self._plan = None                      # grow-only launch-plan buffer (mbrl_fd_plan), owned by this engine
 
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
@@ -86,8 +87,18 @@ class FdEngine:
             a = fn(P.reshape(-1, n).float()).double()
         return a.reshape(P.shape[:-1] + (self.nu,)).contiguous()
 
+    def _plan_buffer(self, N):
+        need = int(self.L.mbrl_fd_plan_bytes(self.h, N))
+        if need < 0:
+            lib.check(need)
+        if self._plan is None or self._plan.numel() < need:
+            self._plan = torch.empty(need, dtype=torch.uint8, device=self.device)   # torch blocks are 512-byte aligned
+        return self._plan
+
     def fd_jacobians(self, qpos, qvel, ctrl, eps=1e-6, fd_mode=lib.FD_FORWARD, nsteps=1, out=None, policy=None,
-                     ctrl_pert=None):
+                     ctrl_pert=None, planned=False):
+        """planned=False: one launch (mbrl_fd_jacobians_closed_loop).  planned=True: mbrl_fd_plan (nominal rollouts +
+        sort by control flow) then mbrl_fd_jacobians_planned (perturbed rollouts in that order); same results."""
         qpos, qvel, ctrl = self._in(qpos, self.nq), self._in(qvel, self.nv), self._in(ctrl, self.nu)
         N, n, nu = qpos.shape[0], self.n, self.nu
         if qvel.shape[0] != N or ctrl.shape[0] != N:
@@ -102,6 +113,17 @@ class FdEngine:
         o = out or dict(dsds=self._new(N, n, n), dsda=self._new(N, n, nu), drds=self._new(N, n),
                         drda=self._new(N, nu), s_next=self._new(N, n), reward=self._new(N),
                         status=self._new(N, dtype=torch.int32))
+        if planned and N:
+            plan = self._plan_buffer(N)
+            with torch.cuda.device(self.device):
+                lib.check(self.L.mbrl_fd_plan(self.h, N, _ptr(qpos), _ptr(qvel), _ptr(ctrl), int(nsteps), _ptr(plan),
+                                              plan.numel(), _ptr(o["s_next"]), _ptr(o["reward"]), _ptr(o["status"]),
+                                              self._stream()))
+                lib.check(self.L.mbrl_fd_jacobians_planned(
+                    self.h, N, _ptr(qpos), _ptr(qvel), _ptr(ctrl), _ptr(ctrl_pert), float(eps), int(fd_mode), int(nsteps),
+                    _ptr(plan), plan.numel(), _ptr(o["dsds"]), _ptr(o["dsda"]), _ptr(o["drds"]), _ptr(o["drda"]),
+                    _ptr(o["status"]), self._stream()))
+            return o
         with torch.cuda.device(self.device):
             lib.check(self.L.mbrl_fd_jacobians_closed_loop(
                 self.h, N, _ptr(qpos), _ptr(qvel), _ptr(ctrl), _ptr(ctrl_pert), float(eps), int(fd_mode), int(nsteps),
