@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--fd-mode", type=int, default=0)
     ap.add_argument("--cpu-units", type=int, default=16384)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--single-launch", action="store_true", help="time mbrl_fd_jacobians instead of plan + planned")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -120,18 +121,34 @@ def main():
             td.barrier()
         torch.cuda.synchronize()
 
+    # One step = the whole linearisation of the batch: mbrl_fd_plan (nominal rollouts + unit order) and
+    # mbrl_fd_jacobians_planned (the perturbed rollouts: the dominant kernel).  --single-launch times mbrl_fd_jacobians.
+    def step(marks=None):
+        if a.single_launch:
+            eng.fd_jacobians(q, v, c, fd_mode=a.fd_mode, out=out, planned=False)
+        else:
+            eng.fd_plan(q, v, c, out=out)
+            if marks:
+                marks[1].record()
+            eng.fd_planned(q, v, c, out, fd_mode=a.fd_mode)
+
     for _ in range(a.warmup):
-        eng.fd_jacobians(q, v, c, fd_mode=a.fd_mode, out=out)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+        step()
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(a.steps)]
     barrier()
     t0 = time.perf_counter()
-    for s, e in ev:
-        s.record()
-        eng.fd_jacobians(q, v, c, fd_mode=a.fd_mode, out=out)
-        e.record()
+    for m in ev:
+        m[0].record()
+        step(m)
+        m[2].record()
     barrier()
     elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))   # HIP events on the launch stream
+    # HIP events on the launch stream
+    if a.single_launch:
+        plan_ms, kern_ms = 0.0, float(np.mean([m[0].elapsed_time(m[2]) for m in ev]))
+    else:
+        plan_ms = float(np.mean([m[0].elapsed_time(m[1]) for m in ev]))
+        kern_ms = float(np.mean([m[1].elapsed_time(m[2]) for m in ev]))
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         td.all_reduce(t, op=td.ReduceOp.MAX)
@@ -142,10 +159,11 @@ def main():
         n, nu = eng.n, eng.nu
         qh, vh, ch = q[:64].cpu().numpy(), v[:64].cpu().numpy(), c[:64].cpu().numpy()
         fpu, how = count_flops_per_unit(qh, vh, ch, 10)
-        if a.fd_mode == 1:
-            fpu *= (2 * (n + nu) + 1) / (n + nu + 1)
+        R = 2 * (n + nu) + 1 if a.fd_mode == 1 else n + nu + 1
+        fpu *= R / (n + nu + 1)                      # flops of all R rollouts of a unit
+        fpu_kernel = fpu if a.single_launch else fpu * (R - 1) / R   # the planned kernel runs the perturbed ones only
         bytes_unit = (n + nu) * 8 + (n * n + n * nu + 2 * n + nu + 1) * 8 + 4
-        tflops = fpu * N / (kern_ms * 1e-3) / 1e12
+        tflops = fpu_kernel * N / (kern_ms * 1e-3) / 1e12
         gbs = bytes_unit * N / (kern_ms * 1e-3) / 1e9
         line = {
             "metric": "FD dynamics Jacobians/sec (HalfCheetah, batch x horizon)",
@@ -155,12 +173,15 @@ def main():
             "config": {"workload": "HalfCheetah FD Jacobians, %s differences eps=1e-6, %d units/GPU (batch %d x horizon %d), "
                                    "S2 on-trajectory states" % ("central" if a.fd_mode else "forward (reference parity)",
                                                                 N, BATCH, HORIZON),
+                       "launches": "mbrl_fd_jacobians" if a.single_launch else "mbrl_fd_plan + mbrl_fd_jacobians_planned",
                        "env": ENV, "units_per_gpu": N, "frame_skip": 10, "fd_mode": a.fd_mode,
                        "parallelism": "units sharded over %d GPU(s), no data-path collective" % world},
             "roofline": {"bound": "valu_fp64", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "traffic": recorded_traffic(N),
-                         "kernel": "rollout_kernel<MdlHalfCheetah, false>", "kernel_ms": kern_ms,
-                         "flops_per_unit": fpu, "flops_source": how,
+                         "kernel": "rollout_kernel<MdlHalfCheetah, false>" +
+                                   ("" if a.single_launch else " launched by mbrl_fd_jacobians_planned"),
+                         "kernel_ms": kern_ms, "plan_ms": plan_ms,
+                         "flops_per_unit": fpu, "flops_per_unit_in_kernel": fpu_kernel, "flops_source": how,
                          "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                  "bytes_per_unit": bytes_unit},
                          "note": "path is fp64-VALU bound (arithmetic intensity ~%d flop/B); neither HBM nor MFMA binds"

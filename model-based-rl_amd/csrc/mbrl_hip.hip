@@ -102,6 +102,27 @@ struct WaveMap {
     }
 };
 
+// ---- launch plan (mbrl_fd_plan): the nominal rollouts, their control-flow keys and the sorted unit order ----
+// Segments of the caller's plan buffer, each 256-byte aligned:
+//   key_in u32[N] | idx_in u32[N] | key_out u32[N] | perm u32[N] | nom_s f64[N * ns] | nom_r f64[N] | radix-sort scratch
+// The kernel gets the buffer as ONE pointer and derives the segments where it uses them (kernel arguments stay live in
+// scalar registers for the whole rollout, and those are short).
+constexpr int kKeyBits = 30;   // 3 bits x the last 10 mj_forward calls (Lean::key)
+constexpr int PLAN_NONE = 0, PLAN_WRITE = 1, PLAN_READ = 2;
+struct PlanOffsets {
+    size_t key_in, idx_in, key_out, perm, nom_s, nom_r, end;
+    __host__ __device__ static size_t up(size_t x) { return (x + 255) & ~size_t(255); }
+    __host__ __device__ PlanOffsets(int64_t N, int ns) {
+        const size_t w = up(sizeof(uint32_t) * size_t(N));
+        key_in = 0; idx_in = w; key_out = 2 * w; perm = 3 * w; nom_s = 4 * w;
+        nom_r = nom_s + up(sizeof(double) * size_t(N) * size_t(ns));
+        end = nom_r + up(sizeof(double) * size_t(N));
+    }
+};
+struct PlanLayout {
+    size_t sort_tmp, sort_bytes, total;
+};
+
 // STEP_NAME only gives plain-step launches their own symbol in profiler output (the body does not use it,
 // so both instantiations are compiled from identical IR; tests/test_gpu_parity.py checks the bits).
 template <class M, bool STEP_NAME>
@@ -114,11 +135,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_sk
                                                           double *__restrict__ drda, double *__restrict__ s_next,
                                                           double *__restrict__ qpos_next, double *__restrict__ qvel_next,
                                                           double *__restrict__ reward, uint32_t *__restrict__ status,
-                                                          const uint32_t *__restrict__ perm,
-                                                          const double *__restrict__ nom_s,
-                                                          const double *__restrict__ nom_r,
-                                                          uint32_t *__restrict__ plan_key,
-                                                          uint32_t *__restrict__ plan_idx) {
+                                                          char *__restrict__ plan, int plan_mode) {
     using LY = Layout<M>;
     constexpr int NV = M::NV, NU = M::NU, NS = 2 * NV, ROW = NS + 1, NP = NU + 2 * NV;
     static_assert(kBlock == 64, "one wave per workgroup");
@@ -131,7 +148,8 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_sk
     int u, p, nom;
     bool primary, live;
     int64_t unit;
-    if (perm) {
+    const bool planned = plan_mode == PLAN_READ;
+    if (planned) {
         // planned launch (mbrl_fd_jacobians_planned): perturbed rollouts only, units in the planner's order, every
         // lane busy; the nominal results come from the plan (nom_s, nom_r).  2 NP is even, so a central couple
         // (+eps on the even lane, -eps on the next) never straddles two waves.
@@ -139,7 +157,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_sk
         const int64_t slot = central ? g / (2 * NP) : g / NP;
         p = 1 + int(g - slot * (central ? 2 * NP : NP));
         live = slot < N;
-        unit = live ? int64_t(perm[slot]) : 0;
+        unit = live ? int64_t(reinterpret_cast<const uint32_t *>(plan + PlanOffsets(N, NS).perm)[slot]) : 0;
         nom = 0; primary = true;
     } else {
         const bool mapped = wm.lane(int(blockIdx.x & 1u), t, u, p, nom, primary);
@@ -198,7 +216,11 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_sk
         for (int j = 0; j < NV; j++) { o[j] = S.mem.ld(LY::OQ + j); o[NV + j] = S.mem.ld(LY::OV + j); }
         o[NS] = r;
         st = S.status;
-        if (plan_key) { plan_key[unit] = S.key; plan_idx[unit] = uint32_t(unit); }
+        if (plan_mode == PLAN_WRITE) {
+            const PlanOffsets po(N, NS);
+            reinterpret_cast<uint32_t *>(plan + po.key_in)[unit] = S.key;
+            reinterpret_cast<uint32_t *>(plan + po.idx_in)[unit] = uint32_t(unit);
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < ROW; j++) o[j] = 0.0;
@@ -219,10 +241,16 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_sk
         if (idx < NU) { if (dsda) js = dsda + unit * (NS * NU) + col; if (drda) jr = drda + unit * NU + col; stride = NU; }
         else { if (dsds) js = dsds + unit * (NS * NS) + col; if (drds) jr = drds + unit * NS + col; stride = NS; }
     }
+    const double *nom_s = nullptr, *nom_r = nullptr;
+    if (planned && !central) {
+        const PlanOffsets po(N, NS);
+        nom_s = reinterpret_cast<const double *>(plan + po.nom_s) + unit * NS;
+        nom_r = reinterpret_cast<const double *>(plan + po.nom_r) + unit;
+    }
 #pragma unroll
     for (int j = 0; j < ROW; j++) {
         double base = __shfl(o[j], ref, 64);
-        if (perm && !central) base = j < NS ? nom_s[unit * NS + j] : nom_r[unit];
+        if (nom_s) base = j < NS ? nom_s[j] : *nom_r;
         const double dv = (o[j] - base) / den;
         if (j < NS) { if (js) js[j * stride] = dv; }
         else if (jr) *jr = dv;
@@ -335,50 +363,35 @@ template <class M>
 static int launch_rollouts(const mbrl_model *m, int64_t N, int mode, const double *qpos, const double *qvel,
                            const double *ctrl, const double *ctrl_pert, double eps, int nsteps, double *dsds, double *dsda,
                            double *drds, double *drda, double *s_next, double *qpos_next, double *qvel_next, double *reward,
-                           uint32_t *status, hipStream_t st, const uint32_t *perm = nullptr, const double *nom_s = nullptr,
-                           const double *nom_r = nullptr, uint32_t *plan_key = nullptr, uint32_t *plan_idx = nullptr) {
+                           uint32_t *status, hipStream_t st, char *plan = nullptr, int plan_mode = PLAN_NONE) {
     constexpr int NP = M::NU + 2 * M::NV;
     const bool central = mode == MODE_CENTRAL;
     const WaveMap wm(mode == MODE_STEP ? 1 : (central ? 1 + 2 * NP : 1 + NP), central);
     int64_t blocks = 2 * ((N + wm.upp - 1) / wm.upp);
-    if (perm) blocks = (N * (central ? 2 * NP : NP) + kBlock - 1) / kBlock;
+    const bool planned = plan_mode == PLAN_READ;
+    if (planned) blocks = (N * (central ? 2 * NP : NP) + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffLL) return -2;
     // per-unit status words are OR-ed into HBM by the waves (a unit can span two): start from zero, in stream order
     // (a planned launch ORs into the words its plan launch wrote)
-    if (status && !perm && hipMemsetAsync(status, 0, sizeof(uint32_t) * size_t(N), st) != hipSuccess) return -1;
+    if (status && !planned && hipMemsetAsync(status, 0, sizeof(uint32_t) * size_t(N), st) != hipSuccess) return -1;
     if (mode == MODE_STEP)
         hipLaunchKernelGGL((rollout_kernel<M, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, N, m->frame_skip, nsteps,
                            eps, mode, qpos, qvel, ctrl, ctrl_pert, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward,
-                           status, perm, nom_s, nom_r, plan_key, plan_idx);
+                           status, plan, plan_mode);
     else
         hipLaunchKernelGGL((rollout_kernel<M, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, N, m->frame_skip, nsteps,
                            eps, mode, qpos, qvel, ctrl, ctrl_pert, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward,
-                           status, perm, nom_s, nom_r, plan_key, plan_idx);
+                           status, plan, plan_mode);
     return 0;
 }
 
-// ---- launch plan (mbrl_fd_plan): the nominal rollouts, their control-flow keys and the sorted unit order ----
-// Segments of the caller's plan buffer, each 256-byte aligned:
-//   key_in u32[N] | idx_in u32[N] | key_out u32[N] | perm u32[N] | nom_s f64[N * ns] | nom_r f64[N] | radix-sort scratch
-constexpr int kKeyBits = 30;   // 3 bits x the last 10 mj_forward calls (Lean::key)
-struct PlanLayout {
-    size_t key_in, idx_in, key_out, perm, nom_s, nom_r, sort_tmp, sort_bytes, total;
-};
 static bool plan_layout(int64_t N, int ns, hipStream_t st, PlanLayout &L) {
-    auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
-    size_t o = 0;
-    L.key_in = o; o = up(o + sizeof(uint32_t) * size_t(N));
-    L.idx_in = o; o = up(o + sizeof(uint32_t) * size_t(N));
-    L.key_out = o; o = up(o + sizeof(uint32_t) * size_t(N));
-    L.perm = o; o = up(o + sizeof(uint32_t) * size_t(N));
-    L.nom_s = o; o = up(o + sizeof(double) * size_t(N) * size_t(ns));
-    L.nom_r = o; o = up(o + sizeof(double) * size_t(N));
-    L.sort_tmp = o;
+    L.sort_tmp = PlanOffsets(N, ns).end;
     L.sort_bytes = 0;
     uint32_t *nil = nullptr;
     if (rocprim::radix_sort_pairs(nullptr, L.sort_bytes, nil, nil, nil, nil, size_t(N), 0, kKeyBits, st) != hipSuccess)
         return false;
-    L.total = up(o + L.sort_bytes);
+    L.total = (L.sort_tmp + L.sort_bytes + 255) & ~size_t(255);
     return true;
 }
 
@@ -523,13 +536,14 @@ int mbrl_fd_plan(const mbrl_model *m, int64_t N, const double *qpos, const doubl
     if (plan_bytes < int64_t(L.total))
         return fail(-8, "mbrl_fd_plan: plan buffer too small%s (need %lld bytes, see mbrl_fd_plan_bytes)", "", (long long)L.total);
     char *w = static_cast<char *>(plan);
-    uint32_t *key_in = reinterpret_cast<uint32_t *>(w + L.key_in), *idx_in = reinterpret_cast<uint32_t *>(w + L.idx_in);
-    uint32_t *key_out = reinterpret_cast<uint32_t *>(w + L.key_out), *perm = reinterpret_cast<uint32_t *>(w + L.perm);
-    double *nom_s = reinterpret_cast<double *>(w + L.nom_s), *nom_r = reinterpret_cast<double *>(w + L.nom_r);
+    const PlanOffsets po(N, ns);
+    uint32_t *key_in = reinterpret_cast<uint32_t *>(w + po.key_in), *idx_in = reinterpret_cast<uint32_t *>(w + po.idx_in);
+    uint32_t *key_out = reinterpret_cast<uint32_t *>(w + po.key_out), *perm = reinterpret_cast<uint32_t *>(w + po.perm);
+    double *nom_s = reinterpret_cast<double *>(w + po.nom_s), *nom_r = reinterpret_cast<double *>(w + po.nom_r);
     int rc = 0;
     MBRL_DISPATCH(m->env_id, (rc = launch_rollouts<M>(m, N, MODE_STEP, qpos, qvel, ctrl, nullptr, 0.0, nsteps, nullptr, nullptr,
-                                                      nullptr, nullptr, nom_s, nullptr, nullptr, nom_r, status, st, nullptr,
-                                                      nullptr, nullptr, key_in, idx_in)));
+                                                      nullptr, nullptr, nom_s, nullptr, nullptr, nom_r, status, st, w,
+                                                      PLAN_WRITE)));
     if (rc) return fail(-10, "mbrl_fd_plan: clearing the status words failed");
     if ((rc = check_launch(m, "mbrl_fd_plan"))) return rc;
     size_t tmp = L.sort_bytes;
@@ -560,14 +574,11 @@ int mbrl_fd_jacobians_planned(const mbrl_model *m, int64_t N, const double *qpos
     PlanLayout L;
     if (!plan_layout(N, m->nq + m->nv, st, L)) return fail(-10, "mbrl_fd_jacobians_planned: sort size query failed");
     if (plan_bytes < int64_t(L.total)) return fail(-8, "mbrl_fd_jacobians_planned: plan buffer too small");
-    const char *w = static_cast<const char *>(plan);
     int rc = 0;
     MBRL_DISPATCH(m->env_id,
                   (rc = launch_rollouts<M>(m, N, fd_mode == MBRL_FD_CENTRAL ? MODE_CENTRAL : MODE_FORWARD, qpos, qvel, ctrl,
                                            ctrl_pert, eps, nsteps, dsds, dsda, drds, drda, nullptr, nullptr, nullptr, nullptr,
-                                           status, st, reinterpret_cast<const uint32_t *>(w + L.perm),
-                                           reinterpret_cast<const double *>(w + L.nom_s),
-                                           reinterpret_cast<const double *>(w + L.nom_r))));
+                                           status, st, static_cast<char *>(const_cast<void *>(plan)), PLAN_READ)));
     if (rc) return fail(-6, "mbrl_fd_jacobians_planned: N too large for one launch");
     return check_launch(m, "mbrl_fd_jacobians_planned");
 }

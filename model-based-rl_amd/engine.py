@@ -95,10 +95,7 @@ class FdEngine:
             self._plan = torch.empty(need, dtype=torch.uint8, device=self.device)   # torch blocks are 512-byte aligned
         return self._plan
 
-    def fd_jacobians(self, qpos, qvel, ctrl, eps=1e-6, fd_mode=lib.FD_FORWARD, nsteps=1, out=None, policy=None,
-                     ctrl_pert=None, planned=False):
-        """planned=False: one launch (mbrl_fd_jacobians_closed_loop).  planned=True: mbrl_fd_plan (nominal rollouts +
-        sort by control flow) then mbrl_fd_jacobians_planned (perturbed rollouts in that order); same results."""
+    def _fd_args(self, qpos, qvel, ctrl, eps, fd_mode, policy, ctrl_pert):
         qpos, qvel, ctrl = self._in(qpos, self.nq), self._in(qvel, self.nv), self._in(ctrl, self.nu)
         N, n, nu = qpos.shape[0], self.n, self.nu
         if qvel.shape[0] != N or ctrl.shape[0] != N:
@@ -110,20 +107,53 @@ class FdEngine:
             ctrl_pert = torch.as_tensor(ctrl_pert, dtype=torch.float64, device=self.device).contiguous()
             if ctrl_pert.numel() != want:
                 raise ValueError("ctrl_pert has %d elements, expected %d" % (ctrl_pert.numel(), want))
-        o = out or dict(dsds=self._new(N, n, n), dsda=self._new(N, n, nu), drds=self._new(N, n),
-                        drda=self._new(N, nu), s_next=self._new(N, n), reward=self._new(N),
-                        status=self._new(N, dtype=torch.int32))
-        if planned and N:
+        return qpos, qvel, ctrl, ctrl_pert
+
+    def new_outputs(self, N):
+        n, nu = self.n, self.nu
+        return dict(dsds=self._new(N, n, n), dsda=self._new(N, n, nu), drds=self._new(N, n), drda=self._new(N, nu),
+                    s_next=self._new(N, n), reward=self._new(N), status=self._new(N, dtype=torch.int32))
+
+    def fd_plan(self, qpos, qvel, ctrl, nsteps=1, out=None):
+        """First launch of the two-launch linearisation (mbrl_fd_plan): the nominal rollouts (-> out s_next, reward,
+        status) and the order in which mbrl_fd_jacobians_planned walks the units.  The plan lives in this engine's
+        buffer until the next fd_plan call."""
+        qpos, qvel, ctrl, _ = self._fd_args(qpos, qvel, ctrl, 0.0, lib.FD_FORWARD, None, None)
+        N = qpos.shape[0]
+        o = out or self.new_outputs(N)
+        if N:
             plan = self._plan_buffer(N)
             with torch.cuda.device(self.device):
                 lib.check(self.L.mbrl_fd_plan(self.h, N, _ptr(qpos), _ptr(qvel), _ptr(ctrl), int(nsteps), _ptr(plan),
                                               plan.numel(), _ptr(o["s_next"]), _ptr(o["reward"]), _ptr(o["status"]),
                                               self._stream()))
+        return o
+
+    def fd_planned(self, qpos, qvel, ctrl, out, eps=1e-6, fd_mode=lib.FD_FORWARD, nsteps=1, policy=None, ctrl_pert=None):
+        """Second launch (mbrl_fd_jacobians_planned): the perturbed rollouts of the units fd_plan saw, in its order."""
+        qpos, qvel, ctrl, ctrl_pert = self._fd_args(qpos, qvel, ctrl, eps, fd_mode, policy, ctrl_pert)
+        N = qpos.shape[0]
+        if N:
+            plan = self._plan
+            if plan is None:
+                raise lib.MbrlError("fd_planned without fd_plan")
+            with torch.cuda.device(self.device):
                 lib.check(self.L.mbrl_fd_jacobians_planned(
                     self.h, N, _ptr(qpos), _ptr(qvel), _ptr(ctrl), _ptr(ctrl_pert), float(eps), int(fd_mode), int(nsteps),
-                    _ptr(plan), plan.numel(), _ptr(o["dsds"]), _ptr(o["dsda"]), _ptr(o["drds"]), _ptr(o["drda"]),
-                    _ptr(o["status"]), self._stream()))
-            return o
+                    _ptr(plan), plan.numel(), _ptr(out["dsds"]), _ptr(out["dsda"]), _ptr(out["drds"]), _ptr(out["drda"]),
+                    _ptr(out["status"]), self._stream()))
+        return out
+
+    def fd_jacobians(self, qpos, qvel, ctrl, eps=1e-6, fd_mode=lib.FD_FORWARD, nsteps=1, out=None, policy=None,
+                     ctrl_pert=None, planned=True):
+        """calculate_gradients for N units (backward.py:343-480).  planned=True (default): mbrl_fd_plan then
+        mbrl_fd_jacobians_planned; planned=False: the single launch mbrl_fd_jacobians_closed_loop.  Same bits."""
+        qpos, qvel, ctrl, ctrl_pert = self._fd_args(qpos, qvel, ctrl, eps, fd_mode, policy, ctrl_pert)
+        N = qpos.shape[0]
+        o = out or self.new_outputs(N)
+        if planned:
+            self.fd_plan(qpos, qvel, ctrl, nsteps, o)
+            return self.fd_planned(qpos, qvel, ctrl, o, eps, fd_mode, nsteps, ctrl_pert=ctrl_pert)
         with torch.cuda.device(self.device):
             lib.check(self.L.mbrl_fd_jacobians_closed_loop(
                 self.h, N, _ptr(qpos), _ptr(qvel), _ptr(ctrl), _ptr(ctrl_pert), float(eps), int(fd_mode), int(nsteps),

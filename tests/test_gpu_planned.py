@@ -1,0 +1,137 @@
+"""GPU: the two-launch linearisation (mbrl_fd_plan + mbrl_fd_jacobians_planned, include/mbrl.h) against the single
+launch mbrl_fd_jacobians_closed_loop -- the same rollouts in another order, so every output must agree BIT FOR BIT --
+plus the plan buffer's argument checks.  The single launch itself is checked against the oracle and the reference's
+golden vectors in test_gpu_parity.py / test_gpu_ops.py."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _eng(env):
+    import mbrl_amd  # noqa: F401
+    from mbrl_amd.engine import FdEngine
+    return FdEngine(env)
+
+
+def _states(e, N, seed):
+    """Mixed batch: reset-like states, then the same advanced a random number of steps (contacts, limits)."""
+    import torch
+    from mbrl_amd import workloads
+    q, v, c = workloads.s2(e, N, seed=seed, horizon=8)
+    return q, v, c
+
+
+@pytest.mark.parametrize("fd_mode", [0, 1])
+@pytest.mark.parametrize("env", util.ENVS)
+def test_planned_equals_single_launch(env, fd_mode):
+    import torch
+    e = _eng(env)
+    for N in (1, 3, 67, 1500):
+        q, v, c = _states(e, N, seed=N)
+        a = e.fd_jacobians(q, v, c, fd_mode=fd_mode, planned=False)
+        b = e.fd_jacobians(q, v, c, fd_mode=fd_mode, planned=True)
+        torch.cuda.synchronize()
+        for k in a:
+            assert torch.equal(a[k], b[k]), (env, fd_mode, N, k)
+
+
+def test_planned_closed_loop_and_plan_reuse():
+    """One plan serves forward, central and closed-loop launches on the same inputs."""
+    import torch
+    e = _eng("HalfCheetahEnv")
+    N = 333
+    q, v, c = _states(e, N, seed=5)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    cp = torch.rand((N, e.n, e.nu), generator=g, dtype=torch.float64).mul(2).sub(1).cuda()
+    out = e.fd_plan(q, v, c)
+    for kw in (dict(fd_mode=0), dict(fd_mode=1), dict(fd_mode=0, ctrl_pert=cp)):
+        ref = e.fd_jacobians(q, v, c, planned=False, **kw)
+        st0 = out["status"].clone()
+        got = e.fd_planned(q, v, c, out, **kw)
+        torch.cuda.synchronize()
+        for k in ("dsds", "dsda", "drds", "drda", "s_next", "reward"):
+            assert torch.equal(ref[k], got[k]), (kw.keys(), k)
+        assert torch.equal(ref["status"] | st0, got["status"])      # a planned launch ORs into the plan's status words
+
+
+def test_planned_status_and_optional_outputs():
+    import torch
+    from mbrl_amd import lib
+    e = _eng("HalfCheetahEnv")
+    rng = np.random.default_rng(0)
+    N = 41
+    q = rng.uniform(-0.1, 0.1, (N, 9)); v = 0.1 * rng.standard_normal((N, 9)); c = rng.uniform(-1, 1, (N, 6))
+    q[7, 3] = np.nan
+    v[12, 0] = np.inf
+    full = e.fd_jacobians(q, v, c, planned=True)
+    bad = np.zeros(N, bool); bad[[7, 12]] = True
+    assert ((full["status"].cpu().numpy() & lib.ST_NONFINITE) != 0).tolist() == bad.tolist()
+    ok = ~torch.as_tensor(bad)
+    assert torch.isfinite(full["dsds"][ok]).all()
+    # only drds requested, no status, no nominal outputs
+    p = lambda t: C.c_void_p(t.data_ptr())
+    null = C.c_void_p(0)
+    qt, vt, ct = (torch.as_tensor(x, device="cuda") for x in (q, v, c))
+    nbytes = e.L.mbrl_fd_plan_bytes(e.h, N)
+    assert nbytes > 0
+    plan = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    only = torch.full((N, 18), 7.0, dtype=torch.float64, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert e.L.mbrl_fd_plan(e.h, N, p(qt), p(vt), p(ct), 1, p(plan), nbytes, null, null, null, st) == 0
+    assert e.L.mbrl_fd_jacobians_planned(e.h, N, p(qt), p(vt), p(ct), null, 1e-6, 0, 1, p(plan), nbytes,
+                                         null, null, p(only), null, null, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(only[ok], full["drds"][ok])
+
+
+def test_plan_argument_checks():
+    import torch
+    e = _eng("SwimmerEnv")
+    L, h = e.L, e.h
+    N = 10
+    z = lambda *s: torch.zeros(s, dtype=torch.float64, device="cuda")
+    q, v, c = z(N, 5), z(N, 5), z(N, 2)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    null = C.c_void_p(0)
+    nbytes = L.mbrl_fd_plan_bytes(h, N)
+    assert nbytes > 0 and L.mbrl_fd_plan_bytes(h, 0) == 0
+    assert L.mbrl_fd_plan_bytes(h, -1) == -6 and L.mbrl_fd_plan_bytes(None, N) == -1
+    assert L.mbrl_fd_plan_bytes(h, 100 * N) > nbytes
+    plan = torch.empty(nbytes + 512, dtype=torch.uint8, device="cuda")
+    assert L.mbrl_fd_plan(h, N, p(q), p(v), p(c), 1, p(plan), nbytes - 1, null, null, null, null) == -8     # too small
+    assert b"mbrl_fd_plan_bytes" in L.mbrl_last_error()
+    assert L.mbrl_fd_plan(h, N, p(q), p(v), p(c), 1, C.c_void_p(plan.data_ptr() + 8), nbytes, null, null, null, null) == -7
+    assert L.mbrl_fd_plan(h, N, p(q), p(v), p(c), 1, null, nbytes, null, null, null, null) == -1
+    assert L.mbrl_fd_plan(h, 0, null, null, null, 1, null, 0, null, null, null, null) == 0
+    assert L.mbrl_fd_plan(h, N, p(q), p(v), p(c), 1, p(plan), nbytes, null, null, null, null) == 0
+    out = [null] * 5
+    assert L.mbrl_fd_jacobians_planned(h, N, p(q), p(v), p(c), null, 0.0, 0, 1, p(plan), nbytes, *out, null) == -7
+    assert L.mbrl_fd_jacobians_planned(h, N, p(q), p(v), p(c), null, 1e-6, 3, 1, p(plan), nbytes, *out, null) == -7
+    assert L.mbrl_fd_jacobians_planned(h, N, p(q), p(v), p(c), null, 1e-6, 0, 1, p(plan), 16, *out, null) == -8
+    assert L.mbrl_fd_jacobians_planned(h, N, p(q), p(v), p(c), null, 1e-6, 0, 1, null, nbytes, *out, null) == -1
+    assert L.mbrl_fd_jacobians_planned(h, N, p(q), p(v), p(c), null, 1e-6, 0, 1, p(plan), nbytes, *out, null) == 0
+    torch.cuda.synchronize()
+
+
+def test_plan_orders_units_by_solver_key():
+    """The permutation is a permutation, and its keys (segment key_out of the plan) are non-decreasing."""
+    import torch
+    e = _eng("HalfCheetahEnv")
+    N = 5000
+    q, v, c = _states(e, N, seed=9)
+    e.fd_plan(q, v, c)
+    torch.cuda.synchronize()
+    w = (4 * N + 255) // 256 * 256
+    plan = e._plan
+    key_out = plan[2 * w:2 * w + 4 * N].view(torch.int32).cpu().numpy().astype(np.int64)
+    perm = plan[3 * w:3 * w + 4 * N].view(torch.int32).cpu().numpy().astype(np.int64)
+    key_in = plan[0:4 * N].view(torch.int32).cpu().numpy().astype(np.int64)
+    assert sorted(perm.tolist()) == list(range(N))
+    assert (np.diff(key_out) >= 0).all()
+    assert (key_in[perm] == key_out).all()
+    assert len(np.unique(key_in)) > 3            # the batch really mixes control-flow classes
