@@ -104,17 +104,17 @@ struct WaveMap {
 
 // ---- launch plan (mbrl_fd_plan): the nominal rollouts, their control-flow keys and the sorted unit order ----
 // Segments of the caller's plan buffer, each 256-byte aligned:
-//   key_in u32[N] | idx_in u32[N] | key_out u32[N] | perm u32[N] | nom_s f64[N * ns] | nom_r f64[N] | radix-sort scratch
+//   key_in u64[N] | key_out u64[N] | idx_in u32[N] | perm u32[N] | nom_s f64[N * ns] | nom_r f64[N] | radix-sort scratch
 // The kernel gets the buffer as ONE pointer and derives the segments where it uses them (kernel arguments stay live in
 // scalar registers for the whole rollout, and those are short).
-constexpr int kKeyBits = 30;   // 3 bits x the last 10 mj_forward calls (Lean::key)
+constexpr int kKeyBits = 62;   // (3 bits x the last 10 mj_forward calls) of Lean::key, then the same of Lean::key2
 constexpr int PLAN_NONE = 0, PLAN_WRITE = 1, PLAN_READ = 2;
 struct PlanOffsets {
     size_t key_in, idx_in, key_out, perm, nom_s, nom_r, end;
     __host__ __device__ static size_t up(size_t x) { return (x + 255) & ~size_t(255); }
     __host__ __device__ PlanOffsets(int64_t N, int ns) {
-        const size_t w = up(sizeof(uint32_t) * size_t(N));
-        key_in = 0; idx_in = w; key_out = 2 * w; perm = 3 * w; nom_s = 4 * w;
+        const size_t w = up(sizeof(uint32_t) * size_t(N)), w2 = up(sizeof(uint64_t) * size_t(N));
+        key_in = 0; key_out = w2; idx_in = 2 * w2; perm = idx_in + w; nom_s = perm + w;
         nom_r = nom_s + up(sizeof(double) * size_t(N) * size_t(ns));
         end = nom_r + up(sizeof(double) * size_t(N));
     }
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_sk
     if (live) {
         Lean<M, double, LaneMem<double, kBlock>> S;
         S.status = 0;
-        S.key = 0;
+        S.key = 0; S.key2 = 0;
         S.mem.p = lds + t;
         const double *qp = qpos + unit * NV, *vp = qvel + unit * NV, *cp = ctrl + unit * NU;
         double d = eps;
@@ -218,7 +218,8 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_sk
         st = S.status;
         if (plan_mode == PLAN_WRITE) {
             const PlanOffsets po(N, NS);
-            reinterpret_cast<uint32_t *>(plan + po.key_in)[unit] = S.key;
+            reinterpret_cast<uint64_t *>(plan + po.key_in)[unit] =
+                (uint64_t(S.key & 0x3fffffffu) << 32) | uint64_t(S.key2 & 0x3fffffffu);
             reinterpret_cast<uint32_t *>(plan + po.idx_in)[unit] = uint32_t(unit);
         }
     } else {
@@ -389,7 +390,8 @@ static bool plan_layout(int64_t N, int ns, hipStream_t st, PlanLayout &L) {
     L.sort_tmp = PlanOffsets(N, ns).end;
     L.sort_bytes = 0;
     uint32_t *nil = nullptr;
-    if (rocprim::radix_sort_pairs(nullptr, L.sort_bytes, nil, nil, nil, nil, size_t(N), 0, kKeyBits, st) != hipSuccess)
+    uint64_t *nil64 = nullptr;
+    if (rocprim::radix_sort_pairs(nullptr, L.sort_bytes, nil64, nil64, nil, nil, size_t(N), 0, kKeyBits, st) != hipSuccess)
         return false;
     L.total = (L.sort_tmp + L.sort_bytes + 255) & ~size_t(255);
     return true;
@@ -537,8 +539,8 @@ int mbrl_fd_plan(const mbrl_model *m, int64_t N, const double *qpos, const doubl
         return fail(-8, "mbrl_fd_plan: plan buffer too small%s (need %lld bytes, see mbrl_fd_plan_bytes)", "", (long long)L.total);
     char *w = static_cast<char *>(plan);
     const PlanOffsets po(N, ns);
-    uint32_t *key_in = reinterpret_cast<uint32_t *>(w + po.key_in), *idx_in = reinterpret_cast<uint32_t *>(w + po.idx_in);
-    uint32_t *key_out = reinterpret_cast<uint32_t *>(w + po.key_out), *perm = reinterpret_cast<uint32_t *>(w + po.perm);
+    uint64_t *key_in = reinterpret_cast<uint64_t *>(w + po.key_in), *key_out = reinterpret_cast<uint64_t *>(w + po.key_out);
+    uint32_t *idx_in = reinterpret_cast<uint32_t *>(w + po.idx_in), *perm = reinterpret_cast<uint32_t *>(w + po.perm);
     double *nom_s = reinterpret_cast<double *>(w + po.nom_s), *nom_r = reinterpret_cast<double *>(w + po.nom_r);
     int rc = 0;
     MBRL_DISPATCH(m->env_id, (rc = launch_rollouts<M>(m, N, MODE_STEP, qpos, qvel, ctrl, nullptr, 0.0, nsteps, nullptr, nullptr,

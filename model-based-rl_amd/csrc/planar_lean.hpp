@@ -320,7 +320,8 @@ struct Lean {
     uint32_t pair_on;
     unsigned status;
     int newton_iters;
-    uint32_t key;            // see forward(); the caller zeroes it
+    uint32_t key, key2;      // see forward(); the caller zeroes them
+    uint32_t ls_iters;
     MBRL_PHASE_MEMBER
 
     // ------------------------------------------------------------------ motion subspace
@@ -1131,6 +1132,7 @@ struct Lean {
                 MBRL_OPAQUE(cand_on); MBRL_OPAQUE(lim_on);
                 T g = a1 + alpha * a2, h = a2;
                 uint32_t nlm, ncm;
+                ls_iters++;
                 line_pass(qacc, sx, alpha, g, h, nlm, ncm);
                 if (nlm == llm && ncm == lcm) { exact = true; break; }   // alpha is the exact root of its own piece
                 llm = nlm; lcm = ncm;
@@ -1184,10 +1186,21 @@ struct Lean {
         MBRL_UNROLL
         for (int j = 0; j < NV; j++) fcon[j] = T(0.0);
         newton_iters = 0;
+        ls_iters = 0;
         if (constrained) solve_constraints();
         // control-flow signature of the rollout: 3 bits per mj_forward (Hessian passes, 0 = unconstrained), latest in the
         // low bits.  Units with equal signatures take the same branches; the launch planner sorts by it (mbrl_fd_plan).
         key = (key << 3) | uint32_t(newton_iters < 7 ? newton_iters : 7);
+#ifndef MBRL_KEY_FINE
+#define MBRL_KEY_FINE 1
+#endif
+        {
+            uint32_t fine = 0;
+            if (MBRL_KEY_FINE == 1) fine = ls_iters < 7 ? ls_iters : 7;
+            if (MBRL_KEY_FINE == 2) { const int ng = __builtin_popcount((cand_on | (cand_on >> 1)) & 0x55555555u); fine = ng < 7 ? ng : 7; }
+            if (MBRL_KEY_FINE == 3) fine = (ls_iters < 3 ? ls_iters : 3) | (lim_on ? 4u : 0u);
+            key2 = (key2 << 3) | fine;
+        }
         MBRL_PIN(qacc, NV); MBRL_PIN(fcon, NV);
         MBRL_PHASE(6);
     }

@@ -126,11 +126,12 @@ def test_plan_orders_units_by_solver_key():
     q, v, c = _states(e, N, seed=9)
     e.fd_plan(q, v, c)
     torch.cuda.synchronize()
-    w = (4 * N + 255) // 256 * 256
+    up = lambda x: (x + 255) // 256 * 256          # segment layout of the plan buffer: csrc/mbrl_hip.hip PlanOffsets
+    w, w2 = up(4 * N), up(8 * N)
     plan = e._plan
-    key_out = plan[2 * w:2 * w + 4 * N].view(torch.int32).cpu().numpy().astype(np.int64)
-    perm = plan[3 * w:3 * w + 4 * N].view(torch.int32).cpu().numpy().astype(np.int64)
-    key_in = plan[0:4 * N].view(torch.int32).cpu().numpy().astype(np.int64)
+    key_in = plan[0:8 * N].view(torch.int64).cpu().numpy()
+    key_out = plan[w2:w2 + 8 * N].view(torch.int64).cpu().numpy()
+    perm = plan[2 * w2 + w:2 * w2 + w + 4 * N].view(torch.int32).cpu().numpy().astype(np.int64)
     assert sorted(perm.tolist()) == list(range(N))
     assert (np.diff(key_out) >= 0).all()
     assert (key_in[perm] == key_out).all()

@@ -1,0 +1,28 @@
+"""How much of the planned kernel's time is still control-flow divergence?  Times it on the bench batch and on a batch
+made of the same units each repeated 64 times (every wave then runs copies of two or three units only)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import mbrl_amd  # noqa: F401
+from mbrl_amd import engine, workloads
+
+def time_planned(e, q, v, c, reps=5):
+    out = e.fd_plan(q, v, c)
+    e.fd_planned(q, v, c, out)
+    t = []
+    for _ in range(reps):
+        a, b, d = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        a.record(); e.fd_plan(q, v, c, out=out); b.record(); e.fd_planned(q, v, c, out); d.record()
+        torch.cuda.synchronize()
+        t.append((a.elapsed_time(b), b.elapsed_time(d)))
+    t.sort(key=lambda x: x[1])
+    return t[len(t) // 2]
+
+e = engine.FdEngine("HalfCheetahEnv", 0, "cuda:0")
+N = 163840
+q, v, c = workloads.s2(e, N, seed=0, horizon=40)
+print("bench batch        plan %.3f ms  kernel %.3f ms" % time_planned(e, q, v, c))
+rep = lambda x: x[: N // 64].repeat_interleave(64, dim=0).contiguous()
+print("64x repeated units plan %.3f ms  kernel %.3f ms" % time_planned(e, rep(q), rep(v), rep(c)))
+rep2 = lambda x: x[: N // 64].repeat(64, 1).contiguous()
+print("same units, tiled  plan %.3f ms  kernel %.3f ms" % time_planned(e, rep2(q), rep2(v), rep2(c)))
