@@ -158,6 +158,8 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_sk
         p = 1 + int(g - slot * (central ? 2 * NP : NP));
         live = slot < N;
         unit = live ? int64_t(reinterpret_cast<const uint32_t *>(plan + PlanOffsets(N, NS).perm)[slot]) : 0;
+        // a plan made for another batch holds arbitrary indices here: never follow one out of the arrays
+        if (unit >= N) { live = false; unit = 0; }
         nom = 0; primary = true;
     } else {
         const bool mapped = wm.lane(int(blockIdx.x & 1u), t, u, p, nom, primary);

@@ -32,6 +32,7 @@ class FdEngine:
         self.env, self.nq, self.nv, self.nu, self.dt = env, nq.value, nv.value, nu.value, dt.value
         self.n = self.nq + self.nv
         self._plan = None                      # grow-only launch-plan buffer (mbrl_fd_plan), owned by this engine
+        self._plan_units = -1                  # batch size the buffer's current plan was made for
 
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
@@ -123,6 +124,7 @@ class FdEngine:
         o = out or self.new_outputs(N)
         if N:
             plan = self._plan_buffer(N)
+            self._plan_units = N
             with torch.cuda.device(self.device):
                 lib.check(self.L.mbrl_fd_plan(self.h, N, _ptr(qpos), _ptr(qvel), _ptr(ctrl), int(nsteps), _ptr(plan),
                                               plan.numel(), _ptr(o["s_next"]), _ptr(o["reward"]), _ptr(o["status"]),
@@ -135,8 +137,8 @@ class FdEngine:
         N = qpos.shape[0]
         if N:
             plan = self._plan
-            if plan is None:
-                raise lib.MbrlError("fd_planned without fd_plan")
+            if plan is None or self._plan_units != N:
+                raise lib.MbrlError("fd_planned: no plan for a batch of %d units (call fd_plan on the same inputs first)" % N)
             with torch.cuda.device(self.device):
                 lib.check(self.L.mbrl_fd_jacobians_planned(
                     self.h, N, _ptr(qpos), _ptr(qvel), _ptr(ctrl), _ptr(ctrl_pert), float(eps), int(fd_mode), int(nsteps),

@@ -136,3 +136,23 @@ def test_plan_orders_units_by_solver_key():
     assert (np.diff(key_out) >= 0).all()
     assert (key_in[perm] == key_out).all()
     assert len(np.unique(key_in)) > 3            # the batch really mixes control-flow classes
+
+
+def test_planned_launch_needs_a_plan_for_the_same_batch():
+    """The engine refuses a planned launch whose plan was made for another batch size; at the C ABI a stale plan cannot
+    lead the kernel outside the arrays (indices >= N are skipped)."""
+    import torch
+    from mbrl_amd import lib
+    e = _eng("SwimmerEnv")
+    q, v, c = _states(e, 40, seed=1)
+    out = e.fd_plan(q, v, c)
+    with pytest.raises(lib.MbrlError):
+        e.fd_planned(q[:20], v[:20], c[:20], e.new_outputs(20))
+    # C ABI: plan for 40 units, launch for 20 with the same (large enough) buffer -- must not fault
+    p = lambda t: C.c_void_p(t.data_ptr())
+    null = C.c_void_p(0)
+    o = e.new_outputs(20)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert e.L.mbrl_fd_jacobians_planned(e.h, 20, p(q), p(v), p(c), null, 1e-6, 0, 1, p(e._plan), e._plan.numel(),
+                                         p(o["dsds"]), p(o["dsda"]), p(o["drds"]), p(o["drda"]), null, st) == 0
+    torch.cuda.synchronize()
