@@ -33,6 +33,7 @@ class FdEngine:
         self.n = self.nq + self.nv
         self._plan = None                      # grow-only launch-plan buffer (mbrl_fd_plan), owned by this engine
         self._plan_units = -1                  # batch size the buffer's current plan was made for
+        self._schedule = {}                    # (mode, nsteps, closed loop, size class) -> planned schedule is faster
 
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
@@ -146,13 +147,37 @@ class FdEngine:
                     _ptr(out["status"]), self._stream()))
         return out
 
+    def _faster_schedule(self, qpos, qvel, ctrl, ctrl_pert, eps, fd_mode, nsteps, o):
+        """Which of the two schedules is faster for this model, mode and batch size?  They produce the same bits, so
+        the choice is made by running both once on the caller's inputs (first call per size class only) and kept.
+        The plan pays off when the linearisation is long against one latency-bound launch of nominal rollouts:
+        HalfCheetah from ~3e4 units (forward) -- not for the pendulums, nor for small batches."""
+        N = qpos.shape[0]
+        key = (int(fd_mode), int(nsteps), ctrl_pert is not None, max(N, 1).bit_length())
+        if key not in self._schedule:
+            ms = {}
+            for planned in (False, True):
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                for rep in range(2):            # the first run warms up (plan buffer, code)
+                    if rep:
+                        ev[0].record(torch.cuda.current_stream(self.device))
+                    self.fd_jacobians(qpos, qvel, ctrl, eps, fd_mode, nsteps, o, ctrl_pert=ctrl_pert, planned=planned)
+                ev[1].record(torch.cuda.current_stream(self.device))
+                ev[1].synchronize()
+                ms[planned] = ev[0].elapsed_time(ev[1])
+            self._schedule[key] = ms[True] < ms[False]
+        return self._schedule[key]
+
     def fd_jacobians(self, qpos, qvel, ctrl, eps=1e-6, fd_mode=lib.FD_FORWARD, nsteps=1, out=None, policy=None,
-                     ctrl_pert=None, planned=True):
-        """calculate_gradients for N units (backward.py:343-480).  planned=True (default): mbrl_fd_plan then
-        mbrl_fd_jacobians_planned; planned=False: the single launch mbrl_fd_jacobians_closed_loop.  Same bits."""
+                     ctrl_pert=None, planned=None):
+        """calculate_gradients for N units (backward.py:343-480).  planned=True: mbrl_fd_plan then
+        mbrl_fd_jacobians_planned; planned=False: the single launch mbrl_fd_jacobians_closed_loop; None (default): the
+        faster of the two for this model / mode / batch size (measured once, see _faster_schedule).  Same bits."""
         qpos, qvel, ctrl, ctrl_pert = self._fd_args(qpos, qvel, ctrl, eps, fd_mode, policy, ctrl_pert)
         N = qpos.shape[0]
         o = out or self.new_outputs(N)
+        if planned is None:
+            planned = N >= 1024 and self._faster_schedule(qpos, qvel, ctrl, ctrl_pert, eps, fd_mode, nsteps, o)
         if planned:
             self.fd_plan(qpos, qvel, ctrl, nsteps, o)
             return self.fd_planned(qpos, qvel, ctrl, o, eps, fd_mode, nsteps, ctrl_pert=ctrl_pert)
