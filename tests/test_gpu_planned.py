@@ -40,6 +40,21 @@ def test_planned_equals_single_launch(env, fd_mode):
             assert torch.equal(a[k], b[k]), (env, fd_mode, N, k)
 
 
+@pytest.mark.parametrize("env", ["HalfCheetahEnv", "HopperEnv", "InvertedDoublePendulumEnv"])
+def test_planned_equals_single_launch_two_env_steps(env):
+    """cfg.MODEL.NSTEPS_FOR_BACKWARD = 2 (backward.py:359): both launches run two env steps per rollout."""
+    import torch
+    e = _eng(env)
+    q, v, c = _states(e, 500, seed=3)
+    a = e.fd_jacobians(q, v, c, nsteps=2, planned=False)
+    b = e.fd_jacobians(q, v, c, nsteps=2, planned=True)
+    one = e.fd_jacobians(q, v, c, nsteps=1, planned=True)
+    torch.cuda.synchronize()
+    for k in a:
+        assert torch.equal(a[k], b[k]), (env, k)
+    assert not torch.equal(a["s_next"], one["s_next"])
+
+
 def test_planned_closed_loop_and_plan_reuse():
     """One plan serves forward, central and closed-loop launches on the same inputs."""
     import torch
