@@ -24,6 +24,7 @@ def needs_build():
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "modelspec.py"),
                                                        os.path.join(HERE, "compile_planar.py"),
+                                                       os.path.abspath(__file__),       # the compiler flags live here
                                                        os.path.join(HERE, "..", "include", "mbrl.h")]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
@@ -36,6 +37,8 @@ def needs_build():
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed",
                "-mllvm", "-pragma-unroll-threshold=1000000", "-mllvm", "-disable-machine-licm",
                "-mllvm", "-amdgpu-use-amdgpu-trackers=1",   # GCN register-pressure trackers in the scheduler: ~30 % fewer AGPR copies
+               "-mllvm", "-amdgpu-sched-strategy=max-ilp",  # occupancy is pinned at one wave per SIMD anyway: schedule for
+                                                            # latency, not for registers (-2.7 %; iterative-ilp, minreg slower)
                "-fno-honor-nans", "-fno-honor-infinities", "-fno-signed-zeros"]
 
 
