@@ -1,16 +1,18 @@
 // mbrl_hip.hip -- HIP kernels (gfx950) + C ABI (include/mbrl.h) for the FD linearisation path.
 //
-// Work decomposition (MI355X, wave64):
-//   * one LANE per rollout (= one perturbed copy of one unit); a unit's 1+nu+nv+nq rollouts sit
-//     in consecutive lanes, so the lanes of a wave are perturbations of at most a few nominal
-//     states and follow the same contact / Newton control flow;
-//   * a 256-thread workgroup owns UPB = 256 / R whole units; rollout results meet in LDS and the
-//     workgroup writes that block of Jacobians with fully coalesced stores (the outputs of
-//     consecutive units are contiguous in every output array);
-//   * the path is fp64-VALU bound (~1 MFLOP per HalfCheetah unit vs 4 KB of HBM traffic); the per-lane
-//     simulator (planar_lean.hpp) keeps its hot working set in registers and its cold / lane-indexed
-//     state (q, v, ctrl, active limit and contact rows) in a lane-interleaved LDS column, which the
-//     result staging buffer re-uses once the rollouts are done.
+// Work decomposition (MI355X, wave64; DESIGN.md 3.1):
+//   * one LANE per rollout (= one perturbed copy of one unit); the path is fp64-VALU bound (~1 MFLOP per HalfCheetah
+//     unit vs 4 KB of HBM traffic), the per-lane simulator (planar_lean.hpp) keeps its hot working set in registers
+//     (one wave per SIMD) and its lane-indexed state (q, v, ctrl, active limit and contact rows) in a
+//     lane-interleaved LDS column;
+//   * a workgroup is ONE wave, so waves never wait for each other;
+//   * single launch (mbrl_fd_jacobians): a unit's 1+nu+nv+nq rollouts sit in consecutive lanes, two consecutive waves
+//     share one unit to keep the lanes full (WaveMap), every perturbed lane differences against the nominal lane of
+//     its own wave with a lane shuffle and writes its Jacobian column straight from registers;
+//   * two launches (mbrl_fd_plan + mbrl_fd_jacobians_planned): the nominal rollouts run first, one lane each, and
+//     leave their results and a control-flow key per unit in the caller's plan buffer; the units are radix-sorted by
+//     key; the second launch runs only the perturbed rollouts, in that order, every lane busy, waves of like units.
+//   All of these run the same rollout_kernel body, so their results agree bit for bit.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
