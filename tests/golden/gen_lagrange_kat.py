@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""Known-answer vectors for the articulated planar trees (Hopper, Walker2d, HalfCheetah) in free flight.
+
+A third formulation, independent of the oracle (3-D recursive spatial algebra) and of the kernel (planar
+composite-rigid-body recursion): the equations of motion from the Lagrangian.  Body poses P(q) = (x, z, angle) of
+every body's centre of mass come from plain forward kinematics written here; everything else is automatic
+differentiation in float64 (torch):
+    M(q)  = J^T W J + diag(armature),  J = dP/dq,  W = diag(m, m, I_yy) per body
+    C_k   = sum_ij (dM_ki/dq_j - 1/2 dM_ij/dq_k) qd_i qd_j
+    V(q)  = sum_b m_b g z_b + sum_j 1/2 k_j q_j^2
+    Q_j   = gear_j clip(ctrl) - damping_j qd_j
+    qacc  = M^-1 (Q - dV/dq - C)
+The states float 5 m above the floor (no contact) and stay inside the joint ranges (no limit rows), so qacc is what
+mj_forward returns.  Body constants come from this script's own capsule formulas (MuJoCo 2.0 capsule volume
+pi r^2 (h + r), as in gen_sympy_kat.py) over the transcription in modelspec.py.
+Output: tests/golden/kat_lagrange.npz  (<env>_q, _v, _c, _qacc, _M).
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+import mbrl_amd  # noqa: F401,E402
+from mbrl_amd import modelspec  # noqa: E402
+
+torch.set_default_dtype(torch.float64)
+G = 9.81
+
+
+def capsule(a, b, r, rho):
+    h = math.dist(a, b)
+    mc, ms = rho * math.pi * r * r * h, rho * math.pi * r ** 3
+    i_pe = mc * (3 * r * r + h * h) / 12 + ms * (2 * r * r / 5 + h * h / 4 + 3 * h * r / 8)
+    return mc + ms, i_pe, ((a[0] + b[0]) / 2, (a[2] + b[2]) / 2)
+
+
+def body_constants(m):
+    """mass, inertia about the com (y axis), com in the body frame (x, z) -- scaled by settotalmass."""
+    out = []
+    for b in m["bodies"]:
+        parts = [capsule(g["a"], g["b"], g["radius"], g["density"]) for g in b["geoms"]]
+        mass = sum(p[0] for p in parts)
+        cx = sum(p[0] * p[2][0] for p in parts) / mass
+        cz = sum(p[0] * p[2][1] for p in parts) / mass
+        iyy = sum(p[1] + p[0] * ((p[2][0] - cx) ** 2 + (p[2][1] - cz) ** 2) for p in parts)
+        out.append([mass, iyy, cx, cz])
+    if m["settotalmass"]:
+        s = m["settotalmass"] / sum(o[0] for o in out)
+        for o in out:
+            o[0] *= s; o[1] *= s
+    return out
+
+
+def rot(th, x, z):
+    """rotation about +y by th: +z turns towards +x"""
+    c, s = torch.cos(th), torch.sin(th)
+    return c * x + s * z, -s * x + c * z
+
+
+def poses(m, consts, q):
+    """(x, z, angle) of every body's centre of mass, stacked."""
+    frames, out, k = [], [], 0
+    for b, (mass, iyy, cx, cz) in zip(m["bodies"], consts):
+        if b["parent"] < 0:
+            ox, oz, th = torch.zeros(()), torch.zeros(()), torch.zeros(())
+            px, pz = b["pos"][0], b["pos"][2]
+        else:
+            ox, oz, th = frames[b["parent"]]
+            px, pz = b["pos"][0], b["pos"][2]
+        dx, dz = rot(th, torch.tensor(px), torch.tensor(pz))
+        ox, oz = ox + dx, oz + dz
+        for j in b["joints"]:
+            d = q[k] - j["ref"]
+            k += 1
+            if j["type"] == "slide":
+                ax, az = rot(th, torch.tensor(j["axis"][0]), torch.tensor(j["axis"][2]))
+                ox, oz = ox + d * ax, oz + d * az
+            else:
+                ax_, az_ = rot(th, torch.tensor(j["pos"][0]), torch.tensor(j["pos"][2]))   # anchor, world offset
+                anx, anz = ox + ax_, oz + az_
+                th = th + d * j["axis"][1]
+                bx, bz = rot(th, torch.tensor(j["pos"][0]), torch.tensor(j["pos"][2]))
+                ox, oz = anx - bx, anz - bz
+        frames.append((ox, oz, th))
+        gx, gz = rot(th, torch.tensor(cx), torch.tensor(cz))
+        out += [ox + gx, oz + gz, th]
+    return torch.stack(out)
+
+
+def qacc_of(m, q, v, c):
+    consts = body_constants(m)
+    joints = [j for b in m["bodies"] for j in b["joints"]]
+    names = [j["name"] for j in joints]
+    W = torch.tensor([w for (mass, iyy, _, _) in consts for w in (mass, mass, iyy)])
+    arm = torch.tensor([j["armature"] for j in joints])
+    kst = torch.tensor([j["stiffness"] for j in joints])
+    dmp = torch.tensor([j["damping"] for j in joints])
+    mz = torch.tensor([w for (mass, _, _, _) in consts for w in (0.0, mass, 0.0)])
+
+    def M_of(qq):
+        J = torch.autograd.functional.jacobian(lambda x: poses(m, consts, x), qq, create_graph=True)
+        return J.T @ (W[:, None] * J) + torch.diag(arm)
+
+    def V_of(qq):
+        return G * (mz * poses(m, consts, qq)).sum() + 0.5 * (kst * qq * qq).sum()
+
+    q, v = torch.tensor(q), torch.tensor(v)
+    Mq = M_of(q)
+    dM = torch.autograd.functional.jacobian(M_of, q)            # [k, i, j] = dM_ki / dq_j
+    Cv = torch.einsum("kij,i,j->k", dM, v, v) - 0.5 * torch.einsum("ijk,i,j->k", dM, v, v)
+    dV = torch.autograd.functional.jacobian(V_of, q)
+    Q = -dmp * v
+    for a, u in zip(m["actuators"], c):
+        if a["ctrllimited"]:
+            u = min(max(u, a["ctrlrange"][0]), a["ctrlrange"][1])
+        Q[names.index(a["joint"])] += a["gear"] * u
+    return torch.linalg.solve(Mq, Q - dV - Cv).detach().numpy(), Mq.detach().numpy()
+
+
+def main():
+    rng = np.random.default_rng(7)
+    out = {}
+    for env in ("HopperEnv", "Walker2dEnv", "HalfCheetahEnv"):
+        m = modelspec.MODELS[env]
+        joints = [j for b in m["bodies"] for j in b["joints"]]
+        nv, nu = len(joints), len(m["actuators"])
+        Q, V, C, A, MM = [], [], [], [], []
+        for _ in range(12):
+            q = np.zeros(nv)
+            for i, j in enumerate(joints):
+                if j["limited"]:
+                    lo, hi = j["range"]
+                    q[i] = rng.uniform(lo + 0.15 * (hi - lo), hi - 0.15 * (hi - lo))
+                else:
+                    q[i] = j["ref"] + rng.uniform(-0.5, 0.5)
+            q[1] += 5.0                                     # root z: far above the floor
+            v = rng.standard_normal(nv)
+            c = rng.uniform(-1.2, 1.2, nu)                  # some beyond the control range: exercises the clamp
+            a, Mq = qacc_of(m, q, v, c)
+            Q.append(q); V.append(v); C.append(c); A.append(a); MM.append(Mq)
+        pre = env[:-3].lower()
+        out.update({pre + "_q": np.array(Q), pre + "_v": np.array(V), pre + "_c": np.array(C),
+                    pre + "_qacc": np.array(A), pre + "_M": np.array(MM)})
+        print(env, "qacc range", np.abs(np.array(A)).max())
+    np.savez(os.path.join(HERE, "kat_lagrange.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()

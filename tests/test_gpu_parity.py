@@ -116,3 +116,26 @@ def test_saturated_controls_give_zero_action_columns(torch_cuda):
     out = e.fd_jacobians(q, v, c)
     assert float(out["dsda"].abs().max()) == 0.0
     assert float(out["drda"].abs().min()) > 0.0
+
+
+@pytest.mark.parametrize("env,pre", [("HopperEnv", "hopper"), ("HalfCheetahEnv", "halfcheetah")])
+def test_step_kernel_matches_lagrangian_free_flight(env, pre, torch_cuda):
+    """One mj_step of the HIP step kernel against the automatic-differentiation Lagrangian (tests/golden/
+    gen_lagrange_kat.py: independent of oracle and kernel): v' = v + h (M + h D)^-1 M qacc, q' = q + h v'."""
+    import os
+    import mbrl_amd  # noqa: F401
+    from mbrl_amd import modelspec
+    from mbrl_amd.engine import FdEngine
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "kat_lagrange.npz"))
+    m = modelspec.MODELS[env]
+    damp = np.array([j["damping"] for b in m["bodies"] for j in b["joints"]])
+    h = m["timestep"]
+    e = FdEngine(env, frame_skip=1)
+    q, v, c = G[pre + "_q"], G[pre + "_v"], G[pre + "_c"]
+    qn, vn, r, st = e.step(q, v, c)
+    assert int((st != 0).sum()) == 0
+    for k in range(len(q)):
+        M, a = G[pre + "_M"][k], G[pre + "_qacc"][k]
+        v1 = v[k] + h * np.linalg.solve(M + h * np.diag(damp), M @ a)
+        assert np.abs(vn[k].cpu().numpy() - v1).max() <= 1e-12 * (1 + np.abs(v1).max())
+        assert np.abs(qn[k].cpu().numpy() - (q[k] + h * v1)).max() <= 1e-13 * (1 + np.abs(q[k]).max())

@@ -1,6 +1,10 @@
-"""CPU: known-answer physics.  Closed-form cart-pole / double cart-pole accelerations derived with sympy
-from the Lagrangian (tests/golden/gen_sympy_kat.py -- independent of the oracle and of the kernel) vs the
-oracle's mj_forward and vs the kernel's per-lane simulator built for the host (SURVEY.md 8c pin (2))."""
+"""CPU: known-answer physics (SURVEY.md 8c pin (2)), vs the oracle's mj_forward and vs the kernel's per-lane simulator
+built for the host.  Two independent sources:
+  * closed-form cart-pole / double cart-pole accelerations derived with sympy from the Lagrangian
+    (tests/golden/gen_sympy_kat.py);
+  * Hopper, Walker2d and HalfCheetah in free flight from an automatic-differentiation Lagrangian over plain forward
+    kinematics (tests/golden/gen_lagrange_kat.py): mass matrix, Coriolis/centrifugal terms, gravity, joint springs,
+    dampers, armature, actuator gears and the control clamp of the 6-, 9- and 9-dof trees."""
 import ctypes as C
 import os
 
@@ -38,3 +42,55 @@ def test_kernel_simulator_qacc_matches_closed_form(env, pre):
                             fs.ctypes.data_as(dp), fc.ctypes.data_as(dp), C.byref(it), C.byref(na))
         assert rc == 0 and it.value == 0
         assert np.abs(qa - a).max() <= 1e-12 * (1 + np.abs(a).max())
+
+
+LAG = np.load(os.path.join(os.path.dirname(__file__), "golden", "kat_lagrange.npz"))
+TREES = (("HopperEnv", "hopper"), ("Walker2dEnv", "walker2d"), ("HalfCheetahEnv", "halfcheetah"))
+
+
+@pytest.mark.parametrize("env,pre", TREES)
+def test_oracle_matches_lagrangian_trees(env, pre):
+    o = Oracle(env)
+    for q, v, c, a, M in zip(LAG[pre + "_q"], LAG[pre + "_v"], LAG[pre + "_c"], LAG[pre + "_qacc"], LAG[pre + "_M"]):
+        f = o.forward(q, v, c)
+        assert f["nefc"] == 0            # free flight, inside the joint ranges
+        assert np.abs(f["qacc"] - a).max() <= 1e-12 * (1 + np.abs(a).max())
+        Mo = np.tril(f["M"]) + np.tril(f["M"], -1).T
+        assert np.abs(Mo - M).max() <= 1e-13 * np.abs(M).max()
+
+
+@pytest.mark.parametrize("env,pre", TREES)
+def test_kernel_simulator_matches_lagrangian_trees(env, pre):
+    """The kernel's simulator does not form qacc in an unconstrained Euler step (implicit joint damping folds it into
+    the velocity update), so it is checked on what it does form: the smooth generalised force M qacc, and -- for the
+    Euler models -- the velocities after one mj_step, v + h (M + h D)^-1 M qacc, against the Lagrangian's M and qacc."""
+    import __graft_entry__
+    import mbrl_amd  # noqa: F401
+    from mbrl_amd import modelspec
+    L = C.CDLL(__graft_entry__.build_host_twin())
+    i = util.ENVS.index(env)
+    m = modelspec.MODELS[env]
+    damp = np.array([j["damping"] for b in m["bodies"] for j in b["joints"]])
+    h = m["timestep"]
+    for q, v, c, a, M in zip(LAG[pre + "_q"], LAG[pre + "_v"], LAG[pre + "_c"], LAG[pre + "_qacc"], LAG[pre + "_M"]):
+        nv = len(q)
+        qa, fs, fc = np.zeros(nv), np.zeros(nv), np.zeros(nv)
+        it, na = C.c_int(), C.c_int()
+        q, v, c = (np.ascontiguousarray(x, dtype=np.float64) for x in (q, v, c))
+        rc = L.twin_forward(i, q.ctypes.data_as(dp), v.ctypes.data_as(dp), c.ctypes.data_as(dp), qa.ctypes.data_as(dp),
+                            fs.ctypes.data_as(dp), fc.ctypes.data_as(dp), C.byref(it), C.byref(na))
+        assert rc == 0 and it.value == 0 and na.value == 0
+        f = M @ a
+        assert np.abs(fs - f).max() <= 1e-12 * (1 + np.abs(f).max())
+        if m["integrator"] == "RK4":
+            assert np.abs(qa - a).max() <= 1e-12 * (1 + np.abs(a).max())
+        else:
+            qn, vn, r = np.zeros((1, nv)), np.zeros((1, nv)), np.zeros(1)
+            st = np.zeros(1, dtype=np.uint32)
+            L.twin_step(i, 1, C.c_int64(1), q.ctypes.data_as(dp), v.ctypes.data_as(dp), c.ctypes.data_as(dp),
+                        qn.ctypes.data_as(dp), vn.ctypes.data_as(dp), r.ctypes.data_as(dp),
+                        st.ctypes.data_as(C.POINTER(C.c_uint32)))
+            v1 = v + h * np.linalg.solve(M + h * np.diag(damp), f)
+            assert st[0] == 0
+            assert np.abs(vn[0] - v1).max() <= 1e-12 * (1 + np.abs(v1).max())
+            assert np.abs(qn[0] - (q + h * v1)).max() <= 1e-13 * (1 + np.abs(q).max())
