@@ -1221,25 +1221,29 @@ struct Lean {
     }
 
     MBRL_HD void step() {
-        forward();
-        if (!M::RK4) { euler(); MBRL_PHASE(7); return; }
-        // classic RK4; stage i uses only stage i-1 (tableau 1/2, 1/2, 1), weights 1/6 1/3 1/3 1/6
+        if (!M::RK4) { forward(); euler(); MBRL_PHASE(7); return; }
+        // classic RK4; stage i uses only stage i-1 (tableau 1/2, 1/2, 1), weights 1/6 1/3 1/3 1/6.  ONE call site of
+        // forward() for the four stages: inlined twice (first stage + loop) the Walker2d kernel was 97 KB of code,
+        // beyond the 64 KB instruction cache.
         T q0[NV], v0[NV], aq[NV], av[NV];
         MBRL_UNROLL
         for (int j = 0; j < NV; j++) {
             q0[j] = mem.ld(LY::OQ + j); v0[j] = mem.ld(LY::OV + j);
-            aq[j] = T(1.0 / 6) * v0[j]; av[j] = T(1.0 / 6) * qacc[j];
+            aq[j] = T(0.0); av[j] = T(0.0);
         }
         MBRL_NOUNROLL
-        for (int i = 1; i < 4; i++) {
-            const double ai = (i == 3) ? 1.0 : 0.5, bi = (i == 3) ? 1.0 / 6 : 1.0 / 3;
-            MBRL_UNROLL
-            for (int j = 0; j < NV; j++) {
-                const T dv = ai * mem.ld(LY::OV + j), da = ai * qacc[j];
-                mem.st(LY::OQ + j, q0[j] + M::DT * dv);
-                mem.st(LY::OV + j, v0[j] + M::DT * da);
+        for (int i = 0; i < 4; i++) {
+            if (i > 0) {
+                const double ai = (i == 3) ? 1.0 : 0.5;
+                MBRL_UNROLL
+                for (int j = 0; j < NV; j++) {
+                    const T dv = ai * mem.ld(LY::OV + j), da = ai * qacc[j];
+                    mem.st(LY::OQ + j, q0[j] + M::DT * dv);
+                    mem.st(LY::OV + j, v0[j] + M::DT * da);
+                }
             }
             forward();
+            const double bi = (i == 0 || i == 3) ? 1.0 / 6 : 1.0 / 3;
             MBRL_UNROLL
             for (int j = 0; j < NV; j++) { aq[j] = aq[j] + bi * mem.ld(LY::OV + j); av[j] = av[j] + bi * qacc[j]; }
         }
