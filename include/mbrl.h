@@ -30,6 +30,7 @@ extern "C" {
 #define MBRL_ST_NOCONVERGE 2u  /* constraint solver hit its iteration cap */
 #define MBRL_ST_OVERFLOW   4u  /* reserved (contact capacity) */
 #define MBRL_ST_DEGENERATE 8u  /* two capsule axes cross (distance 0): that contact's normal is undefined */
+#define MBRL_ST_BADPLAN    16u /* mbrl_fd_jacobians_planned: the plan was made for another batch (N, nsteps, model) */
 
 #define MBRL_FD_FORWARD 0      /* reference parity: one-sided, (f(x+eps)-f(x))/eps, backward.py:402-406 */
 #define MBRL_FD_CENTRAL 1      /* (f(x+eps)-f(x-eps))/(2 eps) */
@@ -96,7 +97,9 @@ int mbrl_fd_jacobians_closed_loop(const mbrl_model *m, int64_t N, const double *
  * Both take the same N, qpos, qvel, ctrl, nsteps and the same stream (or streams ordered by the caller).  `plan` is
  * caller-owned device memory, 256-byte aligned, of at least mbrl_fd_plan_bytes(m, N) bytes (< 0: error); the library
  * allocates nothing.  A plan can be re-used for several mbrl_fd_jacobians_planned calls on the same inputs (forward and
- * central, open and closed loop).  Results are those of mbrl_fd_jacobians_closed_loop bit for bit. */
+ * central, open and closed loop).  Results are those of mbrl_fd_jacobians_closed_loop bit for bit.  A plan made for
+ * another N, nsteps or model is recognised on the device: every unit's status gets MBRL_ST_BADPLAN, no rollout runs and
+ * the Jacobian outputs are left untouched (with status == NULL the mismatch goes unreported). */
 int64_t mbrl_fd_plan_bytes(const mbrl_model *m, int64_t N);
 int mbrl_fd_plan(const mbrl_model *m, int64_t N, const double *qpos, const double *qvel, const double *ctrl, int nsteps,
                  void *plan, int64_t plan_bytes, double *s_next, double *reward, uint32_t *status, void *hip_stream);

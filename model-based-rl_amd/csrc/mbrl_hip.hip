@@ -106,17 +106,26 @@ struct WaveMap {
 
 // ---- launch plan (mbrl_fd_plan): the nominal rollouts, their control-flow keys and the sorted unit order ----
 // Segments of the caller's plan buffer, each 256-byte aligned:
-//   key_in u64[N] | key_out u64[N] | idx_in u32[N] | perm u32[N] | nom_s f64[N * ns] | nom_r f64[N] | radix-sort scratch
+//   header | key_in u64[N] | key_out u64[N] | idx_in u32[N] | perm u32[N] | nom_s f64[N * ns] | nom_r f64[N] | sort scratch
+// The header names the batch the plan was made for (PlanHeader); a planned launch with other arguments flags every
+// unit MBRL_ST_BADPLAN and runs nothing.
 // The kernel gets the buffer as ONE pointer and derives the segments where it uses them (kernel arguments stay live in
 // scalar registers for the whole rollout, and those are short).
 constexpr int kKeyBits = 62;   // (3 bits x the last 10 mj_forward calls) of Lean::key, then the same of Lean::key2
 constexpr int PLAN_NONE = 0, PLAN_WRITE = 1, PLAN_READ = 2;
+constexpr unsigned ST_BADPLAN = MBRL_ST_BADPLAN;
+struct PlanHeader {
+    unsigned long long magic;   // kPlanMagic
+    long long units;            // N
+    int nsteps, frame_skip, env_id, pad;
+};
+constexpr unsigned long long kPlanMagic = 0x4d42524c504c4e31ull;   // "MBRLPLN1"
 struct PlanOffsets {
     size_t key_in, idx_in, key_out, perm, nom_s, nom_r, end;
     __host__ __device__ static size_t up(size_t x) { return (x + 255) & ~size_t(255); }
     __host__ __device__ PlanOffsets(int64_t N, int ns) {
         const size_t w = up(sizeof(uint32_t) * size_t(N)), w2 = up(sizeof(uint64_t) * size_t(N));
-        key_in = 0; key_out = w2; idx_in = 2 * w2; perm = idx_in + w; nom_s = perm + w;
+        key_in = 256; key_out = key_in + w2; idx_in = key_out + w2; perm = idx_in + w; nom_s = perm + w;
         nom_r = nom_s + up(sizeof(double) * size_t(N) * size_t(ns));
         end = nom_r + up(sizeof(double) * size_t(N));
     }
@@ -151,6 +160,20 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_sk
     bool primary, live;
     int64_t unit;
     const bool planned = plan_mode == PLAN_READ;
+    if (planned) {
+        const PlanHeader *hd = reinterpret_cast<const PlanHeader *>(plan);
+        if (hd->magic != kPlanMagic || hd->units != N || hd->nsteps != nsteps || hd->frame_skip != frame_skip ||
+            hd->env_id != M::ENV_ID) {
+            const int64_t g = int64_t(blockIdx.x) * kBlock + t;     // the first N lanes flag one unit each
+            if (status && g < N) atomicOr(&status[g], ST_BADPLAN);
+            return;
+        }
+    }
+    if (plan_mode == PLAN_WRITE && blockIdx.x == 0 && t == 0) {
+        PlanHeader *hd = reinterpret_cast<PlanHeader *>(plan);
+        hd->magic = kPlanMagic; hd->units = N; hd->nsteps = nsteps; hd->frame_skip = frame_skip; hd->env_id = M::ENV_ID;
+        hd->pad = 0;
+    }
     if (planned) {
         // planned launch (mbrl_fd_jacobians_planned): perturbed rollouts only, units in the planner's order, every
         // lane busy; the nominal results come from the plan (nom_s, nom_r).  2 NP is even, so a central couple

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MBRL_LIB") or os.path.join(HERE, "csrc", "libmbrl_hip.so")   # MBRL_LIB: profiling variants
 
-ST_NONFINITE, ST_NOCONVERGE, ST_OVERFLOW, ST_DEGENERATE = 1, 2, 4, 8
+ST_NONFINITE, ST_NOCONVERGE, ST_OVERFLOW, ST_DEGENERATE, ST_BADPLAN = 1, 2, 4, 8, 16
 FD_FORWARD, FD_CENTRAL = 0, 1
 
 SYMBOLS = ("mbrl_abi_version", "mbrl_model_create", "mbrl_model_destroy", "mbrl_model_dims", "mbrl_step",

@@ -144,9 +144,12 @@ def test_plan_orders_units_by_solver_key():
     up = lambda x: (x + 255) // 256 * 256          # segment layout of the plan buffer: csrc/mbrl_hip.hip PlanOffsets
     w, w2 = up(4 * N), up(8 * N)
     plan = e._plan
-    key_in = plan[0:8 * N].view(torch.int64).cpu().numpy()
-    key_out = plan[w2:w2 + 8 * N].view(torch.int64).cpu().numpy()
-    perm = plan[2 * w2 + w:2 * w2 + w + 4 * N].view(torch.int32).cpu().numpy().astype(np.int64)
+    h = 256                                         # header
+    key_in = plan[h:h + 8 * N].view(torch.int64).cpu().numpy()
+    key_out = plan[h + w2:h + w2 + 8 * N].view(torch.int64).cpu().numpy()
+    perm = plan[h + 2 * w2 + w:h + 2 * w2 + w + 4 * N].view(torch.int32).cpu().numpy().astype(np.int64)
+    head = plan[0:16].view(torch.int64).cpu().numpy()                      # PlanHeader: magic, units, nsteps, frame_skip, env
+    assert head[1] == N and plan[16:28].view(torch.int32).tolist() == [1, 10, 5]
     assert sorted(perm.tolist()) == list(range(N))
     assert (np.diff(key_out) >= 0).all()
     assert (key_in[perm] == key_out).all()
@@ -154,8 +157,8 @@ def test_plan_orders_units_by_solver_key():
 
 
 def test_planned_launch_needs_a_plan_for_the_same_batch():
-    """The engine refuses a planned launch whose plan was made for another batch size; at the C ABI a stale plan cannot
-    lead the kernel outside the arrays (indices >= N are skipped)."""
+    """The engine refuses a planned launch whose plan was made for another batch size; at the C ABI a plan made for
+    another N or nsteps is recognised on the device: every unit is flagged MBRL_ST_BADPLAN and nothing is written."""
     import torch
     from mbrl_amd import lib
     e = _eng("SwimmerEnv")
@@ -166,8 +169,20 @@ def test_planned_launch_needs_a_plan_for_the_same_batch():
     # C ABI: plan for 40 units, launch for 20 with the same (large enough) buffer -- must not fault
     p = lambda t: C.c_void_p(t.data_ptr())
     null = C.c_void_p(0)
-    o = e.new_outputs(20)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    assert e.L.mbrl_fd_jacobians_planned(e.h, 20, p(q), p(v), p(c), null, 1e-6, 0, 1, p(e._plan), e._plan.numel(),
-                                         p(o["dsds"]), p(o["dsda"]), p(o["drds"]), p(o["drda"]), null, st) == 0
+    for N, nsteps in ((20, 1), (40, 2)):
+        o = e.new_outputs(N)
+        o["dsds"].fill_(7.0)
+        o["status"].zero_()
+        assert e.L.mbrl_fd_jacobians_planned(e.h, N, p(q), p(v), p(c), null, 1e-6, 0, nsteps, p(e._plan), e._plan.numel(),
+                                             p(o["dsds"]), p(o["dsda"]), p(o["drds"]), p(o["drda"]), p(o["status"]), st) == 0
+        torch.cuda.synchronize()
+        assert bool((o["status"] == lib.ST_BADPLAN).all()) and bool((o["dsds"] == 7.0).all())
+    # the right arguments still work after the refused launches
+    o = e.new_outputs(40)
+    o["status"].zero_()
+    assert e.L.mbrl_fd_jacobians_planned(e.h, 40, p(q), p(v), p(c), null, 1e-6, 0, 1, p(e._plan), e._plan.numel(),
+                                         p(o["dsds"]), p(o["dsda"]), p(o["drds"]), p(o["drda"]), p(o["status"]), st) == 0
     torch.cuda.synchronize()
+    assert bool((o["status"] == 0).all())
+    assert torch.equal(o["dsds"], e.fd_jacobians(q, v, c, planned=False)["dsds"])
