@@ -141,6 +141,18 @@ def test_closed_loop_fd_matches_reference(path):
     out2 = eng.fd_jacobians(g["qpos"], g["qvel"], g["ctrl"], policy=net)
     out3 = eng.fd_jacobians(g["qpos"], g["qvel"], g["ctrl"], ctrl_pert=cp_gpu)
     assert torch.equal(out2["dsds"], out3["dsds"])
+    # the perturbed float32 states handed to the policy are those of the plain formula float32(s + eps e_j), bit for bit
+    seen = []
+    spy = lambda x: (seen.append(x.clone()), net(x))[1]
+    q64, v64 = eng._in(g["qpos"], eng.nq), eng._in(g["qvel"], eng.nv)
+    s64 = torch.cat([q64, v64], dim=1)
+    colj = [eng.nq + j for j in range(eng.nv)] + list(range(eng.nq))
+    for mode, signs in ((0, (1.0,)), (1, (1.0, -1.0))):
+        seen.clear()
+        eng.perturbed_policy_actions(q64, v64, spy, 1e-6, mode)
+        want = torch.stack([torch.stack([(s64 + sg * 1e-6 * torch.nn.functional.one_hot(torch.tensor(cj), eng.n).to(s64))
+                                         for sg in signs], dim=1) for cj in colj], dim=1)     # [N, n, len(signs), n]
+        assert torch.equal(seen[0], want.reshape(-1, eng.n).float())
     # central differences take [N, nv+nq, 2, nu]
     cpc = eng.perturbed_policy_actions(eng._in(g["qpos"], eng.nq), eng._in(g["qvel"], eng.nv), net, fd_mode=1)
     assert cpc.shape == (len(cp), eng.n, 2, eng.nu)
