@@ -68,6 +68,20 @@ class FdEngine:
                                        _ptr(st), self._stream()))
         return qn, vn, r, st
 
+    def step_into(self, qpos, qvel, ctrl, qpos_next, qvel_next, reward, status):
+        """mbrl_step on caller-owned contiguous float64 / int32 device tensors: no allocation, no copy, no checks
+        beyond shape and layout (the rollout loop calls this once per env step)."""
+        N = qpos.shape[0]
+        for t, w in ((qpos, self.nq), (qvel, self.nv), (ctrl, self.nu), (qpos_next, self.nq), (qvel_next, self.nv)):
+            if t.shape != (N, w) or not t.is_contiguous() or t.dtype != torch.float64:
+                raise ValueError("step_into: expected a contiguous float64 [%d, %d] tensor, got %s %s" %
+                                 (N, w, tuple(t.shape), t.dtype))
+        if reward.shape != (N,) or status.shape != (N,) or not reward.is_contiguous() or not status.is_contiguous():
+            raise ValueError("step_into: reward / status must be contiguous [N]")
+        with torch.cuda.device(self.device):
+            lib.check(self.L.mbrl_step(self.h, N, _ptr(qpos), _ptr(qvel), _ptr(ctrl), _ptr(qpos_next), _ptr(qvel_next),
+                                       _ptr(reward), _ptr(status), self._stream()))
+
     def perturbed_policy_actions(self, qpos, qvel, policy, eps=1e-6, fd_mode=lib.FD_FORWARD):
         """Closed-loop mode (cfg.MODEL.POLICY.NETWORK, backward.py:418-419,460-461): the policy's action at every
         state-perturbed copy of every unit, in backward.py's order (qvel entries, then qpos entries).  The state

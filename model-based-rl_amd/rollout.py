@@ -11,20 +11,31 @@ import torch
 from . import lib
 
 
+def _time_major_buffers(engine, s0, H):
+    """Q [H+1, B, nq], V [H+1, B, nv], R [H, B], S [H, B]: step t reads slice t and writes slice t+1 in place, so the
+    loop allocates and copies nothing."""
+    s0 = torch.as_tensor(s0, dtype=torch.float64, device=engine.device)
+    B, nq = s0.shape[0], engine.nq
+    Q = torch.empty((H + 1, B, nq), dtype=torch.float64, device=engine.device)
+    V = torch.empty((H + 1, B, engine.nv), dtype=torch.float64, device=engine.device)
+    R = torch.empty((H, B), dtype=torch.float64, device=engine.device)
+    S = torch.empty((H, B), dtype=torch.int32, device=engine.device)
+    Q[0], V[0] = s0[:, :nq], s0[:, nq:]
+    return Q, V, R, S
+
+
+def _episode_major(Q, V, R, S):
+    return torch.cat([Q, V], dim=2).permute(1, 0, 2).contiguous(), R.t().contiguous(), S.t().contiguous()
+
+
 def rollout(engine, s0, actions):
     """s0 [B, n], actions [B, H, nu] -> states [B, H+1, n], rewards [B, H], status [B, H]."""
     B, H, _ = actions.shape
-    nq = engine.nq
-    states = torch.empty((B, H + 1, engine.n), dtype=torch.float64, device=engine.device)
-    rewards = torch.empty((B, H), dtype=torch.float64, device=engine.device)
-    status = torch.empty((B, H), dtype=torch.int32, device=engine.device)
-    states[:, 0] = torch.as_tensor(s0, dtype=torch.float64, device=engine.device)
+    Q, V, R, S = _time_major_buffers(engine, s0, H)
+    A = torch.as_tensor(actions, dtype=torch.float64, device=engine.device).permute(1, 0, 2).contiguous()   # [H, B, nu]
     for t in range(H):
-        s = states[:, t]
-        qn, vn, r, st = engine.step(s[:, :nq], s[:, nq:], actions[:, t])
-        states[:, t + 1, :nq], states[:, t + 1, nq:] = qn, vn
-        rewards[:, t], status[:, t] = r, st
-    return states, rewards, status
+        engine.step_into(Q[t], V[t], A[t], Q[t + 1], V[t + 1], R[t], S[t])
+    return _episode_major(Q, V, R, S)
 
 
 def action_gradients(engine, states, actions, c, grad_weights="average", eps=1e-6, fd_mode=lib.FD_FORWARD):
@@ -72,20 +83,13 @@ def rollout_with_policy(engine, agent, model_policy, s0, horizon):
     """Forward pass of one epoch for all episodes together (trainer.py:57-74 + basic.py:29-46): the policy sees
     the DETACHED state (basic.py:38), the step kernel advances every episode.  Returns states [B, H+1, n],
     actions [B, H, nu] (with their autograd graph to the policy parameters), rewards [B, H], status [B, H]."""
-    B = s0.shape[0]
-    nq = engine.nq
-    states = torch.empty((B, horizon + 1, engine.n), dtype=torch.float64, device=engine.device)
-    rewards = torch.empty((B, horizon), dtype=torch.float64, device=engine.device)
-    status = torch.empty((B, horizon), dtype=torch.int32, device=engine.device)
-    states[:, 0] = s0
+    Q, V, R, S = _time_major_buffers(engine, s0, horizon)
     acts = []
     for t in range(horizon):
         agent.set_step_idx(t)
-        s = states[:, t]
-        a = model_policy(s.detach().float()).double()
+        a = model_policy(torch.cat([Q[t], V[t]], dim=1).float()).double()
         acts.append(a)
-        qn, vn, r, st = engine.step(s[:, :nq], s[:, nq:], a.detach())
-        states[:, t + 1, :nq], states[:, t + 1, nq:] = qn, vn
-        rewards[:, t], status[:, t] = r, st
+        engine.step_into(Q[t], V[t], a.detach().contiguous(), Q[t + 1], V[t + 1], R[t], S[t])
+    states, rewards, status = _episode_major(Q, V, R, S)
     agent.set_step_idx(horizon)
     return states, torch.stack(acts, dim=1), rewards, status

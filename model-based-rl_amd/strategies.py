@@ -90,7 +90,11 @@ class VariationalOptimization(nn.Module):
             self.mean = Parameter(torch.from_numpy(m).to(self.device))
         self.sd = Parameter(torch.full(self.dim, float(P.INITIAL_SD), dtype=torch.float64, device=self.device))
         self.initial_clamped_sd = self.clamp_sd(self.sd.detach().clone())
-        self.clamped_action = np.zeros((self.action_dim, self.horizon, self.local_batch), dtype=np.float64)
+        # the record of the last epoch's actions lives on the device ([action_dim, horizon, batch], the reference's
+        # layout); `clamped_action` copies it to the host when somebody looks (no transfer inside the step loop)
+        self._clamped_action = torch.zeros((self.action_dim, self.horizon, self.local_batch), dtype=torch.float64,
+                                           device=self.device)
+        self._sd_positive, self._sd_version = None, -1
         self.optimizer = build_optimizer(cfg, self.named_parameters())
         self.log_prob = torch.zeros(self.local_batch, self.horizon, dtype=torch.float64, device=self.device)
 
@@ -104,8 +108,21 @@ class VariationalOptimization(nn.Module):
     def get_clamped_sd(self):
         return self.clamp_sd(self.sd).detach().cpu().numpy()
 
+    @property
+    def clamped_action(self):
+        return self._clamped_action.cpu().numpy()
+
     def get_clamped_action(self):
         return self.clamped_action
+
+    def _sd_is_positive(self, t):
+        """strategies.py:441: noise is drawn only where the standard deviation is positive.  sd changes once per
+        optimisation step, so the test is made for all t at once when the parameter has changed (one host sync per
+        epoch instead of one per env step)."""
+        if self._sd_version != self.sd._version:
+            self._sd_positive = (self.clamp_sd(self.sd).detach().min(dim=0).values > 0).tolist()
+            self._sd_version = self.sd._version
+        return self._sd_positive[t]
 
     def mean_action(self, state):
         """Deterministic action of a closed-loop policy (what the FD re-query of backward.py:418-419 evaluates)."""
@@ -126,7 +143,7 @@ class VariationalOptimization(nn.Module):
                 mean = mean.expand(state.shape[0], -1)
         if not self.training:
             return self.clamp_action(mean)
-        dist = torch.distributions.Normal(mean, clamped_sd) if float(clamped_sd.detach().min()) > 0 else None
+        dist = torch.distributions.Normal(mean, clamped_sd, validate_args=False) if self._sd_is_positive(t) else None
         if self.batch_size > 1 and dist is not None:
             if batched:      # = dist.rsample(): mean + sd * N(0, 1), with the noise of the global batch sliced to this shard
                 z = torch.randn((self.batch_size, self.action_dim), dtype=torch.float64, device=self.device,
@@ -138,12 +155,12 @@ class VariationalOptimization(nn.Module):
             action = self.clamp_action(mean)
         a = action.detach()
         if batched:
-            self.clamped_action[:, t, :a.shape[0]] = a.T.cpu().numpy()
+            self._clamped_action[:, t, :a.shape[0]] = a.T
             if dist is not None:
                 self.log_prob[:a.shape[0], t] = dist.log_prob(a).sum(dim=-1)
         else:
             e = int(self.episode_idx) - 1
-            self.clamped_action[:, t, e] = a.cpu().numpy()
+            self._clamped_action[:, t, e] = a
             if dist is not None:
                 self.log_prob[e, t] = dist.log_prob(a).sum()
         return action
@@ -225,7 +242,7 @@ class VariationalOptimization(nn.Module):
             nn.utils.clip_grad_value_(self.parameters(), 1)
         self.optimizer.step()
         with torch.no_grad():                      # "Make sure sd is not negative" :357-359
-            self.sd.data[self.sd < self.sd_threshold] = self.sd_threshold
+            self.sd.data.clamp_(min=self.sd_threshold)
         self.log_prob = torch.zeros(self.local_batch, self.horizon, dtype=torch.float64, device=self.device)
         return stats
 

@@ -1,0 +1,26 @@
+"""End-to-end trainer throughput on one GPU: wall time per epoch of do_training for HalfCheetah (VariationalOptimization,
+open loop, horizon 40) at several batch sizes.  An epoch = B episodes x 40 env steps forward + the linearisation of all
+B*40 (s, a) + the backward scan + the optimiser step."""
+import os, sys, tempfile, time, logging
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import mbrl_amd  # noqa: F401
+from mbrl_amd import config, trainer
+
+for B in (64, 1024, 4096, 16384):
+    for epochs in (3, 13):       # the difference of the two runs is 10 steady-state epochs
+        cfg = config.get_cfg_defaults()
+        cfg.merge_from_file(os.path.join(os.path.dirname(__file__), "..", "configs", "half_cheetah.yaml"))
+        cfg.merge_from_list(["MODEL.BATCH_SIZE", str(B), "MODEL.EPOCHS", str(epochs), "LOG.PERIOD", "1000"])
+        cfg.freeze()
+        d = tempfile.mkdtemp()
+        lg = logging.getLogger("quiet%d_%d" % (B, epochs)); lg.setLevel(logging.ERROR)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        trainer.do_training(cfg, lg, d, d, d, 1)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        if epochs == 3:
+            base = dt
+        else:
+            per = (dt - base) / 10
+            print("B %6d: %.1f ms per epoch, %.2f M env steps/s, %.2f M linearised (s, a)/s" %
+                  (B, per * 1e3, B * 40 / per / 1e6, B * 40 / per / 1e6), flush=True)
