@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MBRL_ABI_VERSION 3
+#define MBRL_ABI_VERSION 4
 
 /* per-unit status bits (replace mujoco-py's MujocoException / the reference's asserts,
  * backward.py:371,374) */
@@ -119,6 +119,16 @@ int mbrl_fd_jacobians_planned(const mbrl_model *m, int64_t N, const double *qpos
 int mbrl_vjp_scan(const mbrl_model *m, int64_t B, int H, int grad_weights, const double *dsds,
                   const double *dsda, const double *drds, const double *drda, const double *c, double *da,
                   double *ds0, void *hip_stream);
+
+/* The same with the unit index spelled out: MBRL_EPISODE_MAJOR, unit (b, t) at b*H + t (mbrl_vjp_scan), or
+ * MBRL_TIME_MAJOR, at t*B + b -- the order in which a batched rollout produces its (s_t, a_t), so that the
+ * linearisation of the first time steps can run (on another stream) while the later ones are still being simulated.
+ * c, da and all four Jacobian arrays use the same order; ds0 is [B, n] either way. */
+#define MBRL_EPISODE_MAJOR 0
+#define MBRL_TIME_MAJOR 1
+int mbrl_vjp_scan_layout(const mbrl_model *m, int64_t B, int H, int grad_weights, int layout, const double *dsds,
+                         const double *dsda, const double *drds, const double *drda, const double *c, double *da,
+                         double *ds0, void *hip_stream);
 
 /* Introspection (host only, no GPU call; no counterpart in the reference): how the rollouts of a launch are laid
  * out over the 2 x 64 lanes of a wave pair for a model with the given dimensions.  fd_mode: MBRL_FD_FORWARD, MBRL_FD_CENTRAL, or -1 for

@@ -302,7 +302,8 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_sk
 
 // Backward recurrence of the op chain (mujoco.py:43-104): one thread per (episode, output lane).
 // n <= 18, nu <= 6: each episode is walked by one 32-lane group; lane l owns g[l].
-__global__ __launch_bounds__(kBlock) void vjp_scan_kernel(int64_t B, int H, int n, int nu, int gw,
+// Unit (b, t) sits at index b * sb + t * st of every array: episode-major (sb = H, st = 1) or time-major (sb = 1, st = B).
+__global__ __launch_bounds__(kBlock) void vjp_scan_kernel(int64_t B, int H, int n, int nu, int gw, int64_t sb, int64_t st,
                                                            const double *__restrict__ dsds,
                                                            const double *__restrict__ dsda,
                                                            const double *__restrict__ drds,
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(kBlock) void vjp_scan_kernel(int64_t B, int H, int 
         gs[grp][l] = g;
         __syncthreads();
         if (live) {
-            const int64_t k = b * H + t;
+            const int64_t k = b * sb + t * st;
             const double ct = c[k];
             const double W = double(H - t);
             double wa_r = 1.0, wa_d = 1.0, ws_r = 1.0;  // action weights (reward / dynamics op), state weight (reward op)
@@ -614,7 +615,14 @@ int mbrl_fd_jacobians_planned(const mbrl_model *m, int64_t N, const double *qpos
 
 int mbrl_vjp_scan(const mbrl_model *m, int64_t B, int H, int grad_weights, const double *dsds, const double *dsda,
                   const double *drds, const double *drda, const double *c, double *da, double *ds0, void *hip_stream) {
+    return mbrl_vjp_scan_layout(m, B, H, grad_weights, MBRL_EPISODE_MAJOR, dsds, dsda, drds, drda, c, da, ds0, hip_stream);
+}
+
+int mbrl_vjp_scan_layout(const mbrl_model *m, int64_t B, int H, int grad_weights, int layout, const double *dsds,
+                         const double *dsda, const double *drds, const double *drda, const double *c, double *da,
+                         double *ds0, void *hip_stream) {
     if (!m) return fail(-1, "mbrl_vjp_scan: null model");
+    if (layout != MBRL_EPISODE_MAJOR && layout != MBRL_TIME_MAJOR) return fail(-7, "mbrl_vjp_scan: bad layout");
     if (B < 0 || H < 0) return fail(-6, "mbrl_vjp_scan: negative size");
     if (B == 0 || H == 0) return 0;
     if (!dsds || !dsda || !drds || !drda || !c || !da) return fail(-1, "mbrl_vjp_scan: null buffer");
@@ -622,8 +630,9 @@ int mbrl_vjp_scan(const mbrl_model *m, int64_t B, int H, int grad_weights, const
     if (hipSetDevice(m->device) != hipSuccess) return fail(-4, "mbrl_vjp_scan: hipSetDevice failed");
     const int per = kBlock / 32;
     const unsigned blocks = (unsigned)((B + per - 1) / per);
+    const int64_t sb = layout == MBRL_TIME_MAJOR ? 1 : H, st = layout == MBRL_TIME_MAJOR ? B : 1;
     hipLaunchKernelGGL(vjp_scan_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)hip_stream, B, H, m->nq + m->nv,
-                       m->nu, grad_weights, dsds, dsda, drds, drda, c, da, ds0);
+                       m->nu, grad_weights, sb, st, dsds, dsda, drds, drda, c, da, ds0);
     return check_launch(m, "mbrl_vjp_scan");
 }
 

@@ -52,6 +52,13 @@ class FdEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def side_stream(self):
+        """A second HIP stream of this engine's device (rollout.Linearisation overlaps the FD launches with the serial
+        step launches on it)."""
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
     def _new(self, *shape, dtype=torch.float64):
         return torch.empty(shape, dtype=dtype, device=self.device)
 
@@ -208,13 +215,16 @@ class FdEngine:
                 _ptr(o["reward"]), _ptr(o["status"]), self._stream()))
         return o
 
-    def vjp_scan(self, jac, c, grad_weights="average"):
-        """Backward recurrence over [B, H] stored Jacobians (index b*H + t); c = dL/dreward [B, H]."""
+    def vjp_scan(self, jac, c, grad_weights="average", time_major=False):
+        """Backward recurrence over the stored Jacobians.  Episode-major (default): c = dL/dreward [B, H], unit (b, t) at
+        b*H + t, returns da [B, H, nu].  time_major: c [H, B], unit at t*B + b, returns da [H, B, nu].  ds0 [B, n]."""
         gw = {"none": 0, "average": 1, "prioritise": 2}.get(grad_weights, 0)
         c = torch.as_tensor(c, dtype=torch.float64, device=self.device).contiguous()
-        B, H = c.shape
-        da, ds0 = self._new(B, H, self.nu), self._new(B, self.n)
+        B, H = (c.shape[1], c.shape[0]) if time_major else c.shape
+        da = self._new(H, B, self.nu) if time_major else self._new(B, H, self.nu)
+        ds0 = self._new(B, self.n)
         with torch.cuda.device(self.device):
-            lib.check(self.L.mbrl_vjp_scan(self.h, B, H, gw, _ptr(jac["dsds"]), _ptr(jac["dsda"]), _ptr(jac["drds"]),
-                                           _ptr(jac["drda"]), _ptr(c), _ptr(da), _ptr(ds0), self._stream()))
+            lib.check(self.L.mbrl_vjp_scan_layout(self.h, B, H, gw, lib.TIME_MAJOR if time_major else lib.EPISODE_MAJOR,
+                                                  _ptr(jac["dsds"]), _ptr(jac["dsda"]), _ptr(jac["drds"]),
+                                                  _ptr(jac["drda"]), _ptr(c), _ptr(da), _ptr(ds0), self._stream()))
         return da, ds0

@@ -49,6 +49,45 @@ def action_gradients(engine, states, actions, c, grad_weights="average", eps=1e-
     return da, ds0, jac
 
 
+class Linearisation:
+    """The Jacobians of every (s_t, a_t) of a batched rollout, TIME-MAJOR (unit (b, t) at t*B + b), produced on a second
+    HIP stream while the rollout is still running.
+
+    A step launch of B episodes occupies B/64 waves -- 6 % of the chip for B = 4096 -- and the H of them are serial.
+    The linearisation of time steps [t0, t1) needs only their states and actions, which exist as soon as step t1 - 2
+    has finished, so it is submitted chunk by chunk to a side stream and fills the other SIMDs; by the time the last
+    step is done only the last chunk is outstanding.  The reference has no counterpart (its FD runs inside
+    loss.backward(), trainer.py:77); the results are the same Jacobians."""
+
+    def __init__(self, engine, B, H, eps, fd_mode, policy, chunk):
+        self.eng, self.B, self.H, self.eps, self.fd_mode, self.policy = engine, B, H, eps, fd_mode, policy
+        self.chunk = max(1, int(chunk))
+        self.jac = engine.new_outputs(B * H)
+        self.stream = engine.side_stream()
+        self.next_t = 0
+
+    def submit(self, Q, V, A, t_done):
+        """Called on the rollout's stream after step t_done - 1 was enqueued: linearise the finished chunks."""
+        while self.next_t < self.H and (self.next_t + self.chunk <= t_done or t_done >= self.H):
+            t0, t1 = self.next_t, min(self.H, self.next_t + self.chunk)
+            self.next_t = t1
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.eng.device))
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ready)
+                sl = slice(t0 * self.B, t1 * self.B)
+                out = {k: v[sl] for k, v in self.jac.items()}
+                e = self.eng
+                e.fd_jacobians(Q[t0:t1].reshape(-1, e.nq), V[t0:t1].reshape(-1, e.nv), A[t0:t1].reshape(-1, e.nu),
+                               eps=self.eps, fd_mode=self.fd_mode, out=out, policy=self.policy)
+
+    def wait(self):
+        """Make the current stream wait for everything submitted."""
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        torch.cuda.current_stream(self.eng.device).wait_event(done)
+
+
 class RolloutRewards(torch.autograd.Function):
     """rewards [B, H] of a stored rollout as a differentiable function of (actions [B, H, nu], s0 [B, n]).
 
@@ -58,8 +97,9 @@ class RolloutRewards(torch.autograd.Function):
     backward.py:418-419,460-461).  `grad_weights` is cfg.MODEL.POLICY.GRAD_WEIGHTS."""
 
     @staticmethod
-    def forward(ctx, actions, s0, engine, states, rewards, grad_weights, eps, fd_mode, policy, raise_on_status):
+    def forward(ctx, actions, s0, engine, states, rewards, grad_weights, eps, fd_mode, policy, raise_on_status, lin=None):
         ctx.engine, ctx.gw, ctx.eps, ctx.fd_mode, ctx.policy, ctx.chk = engine, grad_weights, eps, fd_mode, policy, raise_on_status
+        ctx.lin = lin            # Linearisation already under way on the side stream (rollout_with_policy), or None
         ctx.save_for_backward(actions.detach(), states)
         # the reference's reward op rounds through fp32 (torch.Tensor([r]).double(), mujoco.py:38); kept
         return rewards.float().double()
@@ -69,27 +109,45 @@ class RolloutRewards(torch.autograd.Function):
         actions, states = ctx.saved_tensors
         eng = ctx.engine
         B, H, nu = actions.shape
-        s = states[:, :H].reshape(B * H, eng.n)
-        jac = eng.fd_jacobians(s[:, :eng.nq], s[:, eng.nq:], actions.reshape(B * H, nu), eps=ctx.eps, fd_mode=ctx.fd_mode,
-                               policy=ctx.policy)
-        if ctx.chk and int((jac["status"] != 0).sum()):
-            raise lib.MbrlError("FD linearisation flagged %d of %d units (status bits, include/mbrl.h)"
-                                % (int((jac["status"] != 0).sum()), B * H))
-        da, ds0 = eng.vjp_scan(jac, c.contiguous(), ctx.gw)
-        return da, ds0, None, None, None, None, None, None, None, None
+        if ctx.lin is not None:
+            ctx.lin.wait()
+            jac = ctx.lin.jac
+        else:
+            s = states[:, :H].reshape(B * H, eng.n)
+            jac = eng.fd_jacobians(s[:, :eng.nq], s[:, eng.nq:], actions.reshape(B * H, nu), eps=ctx.eps,
+                                   fd_mode=ctx.fd_mode, policy=ctx.policy)
+        if ctx.chk:
+            bad = int((jac["status"] != 0).sum())
+            if bad:
+                raise lib.MbrlError("FD linearisation flagged %d of %d units (status bits, include/mbrl.h)" % (bad, B * H))
+        if ctx.lin is not None:
+            da, ds0 = eng.vjp_scan(jac, c.t().contiguous(), ctx.gw, time_major=True)
+            da = da.permute(1, 0, 2)
+        else:
+            da, ds0 = eng.vjp_scan(jac, c.contiguous(), ctx.gw)
+        return da, ds0, None, None, None, None, None, None, None, None, None
 
 
-def rollout_with_policy(engine, agent, model_policy, s0, horizon):
+def rollout_with_policy(engine, agent, model_policy, s0, horizon, linearise=None):
     """Forward pass of one epoch for all episodes together (trainer.py:57-74 + basic.py:29-46): the policy sees
     the DETACHED state (basic.py:38), the step kernel advances every episode.  Returns states [B, H+1, n],
-    actions [B, H, nu] (with their autograd graph to the policy parameters), rewards [B, H], status [B, H]."""
+    actions [B, H, nu] (with their autograd graph to the policy parameters), rewards [B, H], status [B, H] and --
+    with linearise = dict(eps, fd_mode, policy, chunk) -- the Linearisation running beside the rollout (else None)."""
     Q, V, R, S = _time_major_buffers(engine, s0, horizon)
+    B = Q.shape[1]
+    A = torch.empty((horizon, B, engine.nu), dtype=torch.float64, device=engine.device)
+    lin = Linearisation(engine, B, horizon, **linearise) if linearise else None
     acts = []
     for t in range(horizon):
         agent.set_step_idx(t)
         a = model_policy(torch.cat([Q[t], V[t]], dim=1).float()).double()
         acts.append(a)
-        engine.step_into(Q[t], V[t], a.detach().contiguous(), Q[t + 1], V[t + 1], R[t], S[t])
+        A[t].copy_(a.detach())
+        engine.step_into(Q[t], V[t], A[t], Q[t + 1], V[t + 1], R[t], S[t])
+        if lin is not None:
+            lin.submit(Q, V, A, t + 1)
     states, rewards, status = _episode_major(Q, V, R, S)
     agent.set_step_idx(horizon)
-    return states, torch.stack(acts, dim=1), rewards, status
+    if lin is not None:
+        lin.keep = (Q, V, A)     # the side stream reads these: they live as long as the linearisation does
+    return states, torch.stack(acts, dim=1), rewards, status, lin

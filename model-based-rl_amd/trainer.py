@@ -92,12 +92,17 @@ def do_training(cfg, logger, output_results_dir, output_rec_dir, output_weights_
                 state, reward = model(state)
                 batch_loss[:, t] = -reward.reshape(-1)
         else:
-            states, actions, rewards, status = rollout.rollout_with_policy(eng, agent, policy, s0, H)
-            if int((status != 0).sum()):
-                raise lib.MbrlError("rollout flagged %d steps (status bits, include/mbrl.h)" % int((status != 0).sum()))
+            eps = float(cfg.MODEL.get("FD_EPS", 1e-6))
+            fd_policy = policy if cfg.MODEL.POLICY.NETWORK else None
+            overlap = int(cfg.MODEL.get("FD_OVERLAP_STEPS", 8))     # 0: linearise inside loss.backward(), as the reference
+            states, actions, rewards, status, lin = rollout.rollout_with_policy(
+                eng, agent, policy, s0, H,
+                linearise=dict(eps=eps, fd_mode=fd_mode, policy=fd_policy, chunk=overlap) if overlap > 0 else None)
+            bad = int((status != 0).sum())
+            if bad:
+                raise lib.MbrlError("rollout flagged %d steps (status bits, include/mbrl.h)" % bad)
             r = rollout.RolloutRewards.apply(actions, s0, eng, states, rewards, cfg.MODEL.POLICY.GRAD_WEIGHTS,
-                                             float(cfg.MODEL.get("FD_EPS", 1e-6)), fd_mode,
-                                             policy if cfg.MODEL.POLICY.NETWORK else None, True)
+                                             eps, fd_mode, fd_policy, True, lin)
             batch_loss[:] = -r
         agent.running_sum = 0                                       # trainer.py:76
         loss = policy.optimize(batch_loss, grad_sync=grad_sync if world > 1 else None)   # trainer.py:77

@@ -95,3 +95,43 @@ def test_command_line(tmp_path):
     assert "iter_0.pth" in os.listdir(out / "weights")
     with pytest.raises(KeyError):
         cli.main(["--opts", "MODEL.NO_SUCH_KEY", "1"])
+
+
+@pytest.mark.parametrize("env,weights,network", [("HalfCheetahEnv", "prioritise", False), ("SwimmerEnv", "average", True)])
+def test_overlapped_linearisation_trains_bit_for_bit(env, weights, network, tmp_path):
+    """MODEL.FD_OVERLAP_STEPS: the linearisation submitted chunk by chunk to a side stream while the rollout runs
+    (time-major Jacobians, mbrl_vjp_scan_layout) against the linearisation inside loss.backward() -- same Jacobians,
+    same recurrence, so the trained parameters must be identical (open loop), for chunk sizes that do and do not divide H."""
+    import torch
+    res = {}
+    for chunk in (0, 1, 4, 6, 100):
+        cfg = _cfg(env, B=5, H=6, epochs=3, MODEL__FD_OVERLAP_STEPS=chunk, MODEL__POLICY__GRAD_WEIGHTS=weights,
+                   MODEL__POLICY__NETWORK=network)
+        agent, rows, d = _train(cfg, tmp_path, "c%d" % chunk)
+        res[chunk] = {k: v.cpu() for k, v in agent.policy_net.state_dict().items()}
+    for chunk in (1, 4, 6, 100):
+        for k in res[0]:
+            if network:   # the float32 policy GEMM over a chunk's perturbed states rounds differently from the one over
+                # all of them (other batch shape, other tiling), and 1/eps magnifies it: close, not identical
+                assert torch.allclose(res[0][k], res[chunk][k], rtol=5e-3, atol=1e-5), (chunk, k)
+            else:
+                assert torch.equal(res[0][k], res[chunk][k]), (chunk, k)
+
+
+def test_scan_layouts_agree():
+    """mbrl_vjp_scan_layout: time-major arrays give the transposed result of the episode-major call, bit for bit."""
+    import torch
+    import mbrl_amd  # noqa: F401
+    from mbrl_amd.engine import FdEngine
+    e = FdEngine("HalfCheetahEnv")
+    B, H, n, nu = 7, 5, e.n, e.nu
+    g = torch.Generator(device="cpu").manual_seed(3)
+    rnd = lambda *s: torch.randn(s, generator=g, dtype=torch.float64).cuda()
+    jac = dict(dsds=rnd(B, H, n, n), dsda=rnd(B, H, n, nu), drds=rnd(B, H, n), drda=rnd(B, H, nu))
+    c = rnd(B, H)
+    tm = {k: v.transpose(0, 1).contiguous() for k, v in jac.items()}
+    for gw in ("none", "average", "prioritise"):
+        da, ds0 = e.vjp_scan({k: v.reshape((B * H,) + v.shape[2:]) for k, v in jac.items()}, c, gw)
+        da2, ds02 = e.vjp_scan({k: v.reshape((B * H,) + v.shape[2:]) for k, v in tm.items()}, c.t().contiguous(), gw,
+                               time_major=True)
+        assert torch.equal(da, da2.transpose(0, 1)) and torch.equal(ds0, ds02)
