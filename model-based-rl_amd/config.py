@@ -78,7 +78,7 @@ _DEFAULTS = {
         # additions of this build (not in the reference): FD scheme selection
         "FD_EPS": 1e-6, "FD_MODE": "forward",
         # "fused": H step launches + ONE FD launch over B*H units + one scan per epoch; "ops": the reference's op graph
-        "ENGINE_PATH": "fused", "FD_OVERLAP_STEPS": 8,
+        "ENGINE_PATH": "fused", "FD_OVERLAP_STEPS": 4,
     },
     "MUJOCO": {"ENV": "InvertedPendulumEnv", "ASSETS_PATH": "./mujoco/assets/", "REWARD_SCALE": 1,
                "CLIP_ACTIONS": True, "POOL_SIZE": {}},

@@ -94,7 +94,7 @@ def do_training(cfg, logger, output_results_dir, output_rec_dir, output_weights_
         else:
             eps = float(cfg.MODEL.get("FD_EPS", 1e-6))
             fd_policy = policy if cfg.MODEL.POLICY.NETWORK else None
-            overlap = int(cfg.MODEL.get("FD_OVERLAP_STEPS", 8))     # 0: linearise inside loss.backward(), as the reference
+            overlap = int(cfg.MODEL.get("FD_OVERLAP_STEPS", 4))     # 0: linearise inside loss.backward(), as the reference
             states, actions, rewards, status, lin = rollout.rollout_with_policy(
                 eng, agent, policy, s0, H,
                 linearise=dict(eps=eps, fd_mode=fd_mode, policy=fd_policy, chunk=overlap) if overlap > 0 else None)

@@ -7,11 +7,12 @@ import torch
 import mbrl_amd  # noqa: F401
 from mbrl_amd import config, trainer
 
-for B in (64, 1024, 4096, 16384):
+for B in [int(x) for x in os.environ.get("BATCHES", "64,1024,4096,16384").split(",")]:
     for epochs in (3, 13):       # the difference of the two runs is 10 steady-state epochs
         cfg = config.get_cfg_defaults()
         cfg.merge_from_file(os.path.join(os.path.dirname(__file__), "..", "configs", "half_cheetah.yaml"))
-        cfg.merge_from_list(["MODEL.BATCH_SIZE", str(B), "MODEL.EPOCHS", str(epochs), "LOG.PERIOD", "1000"])
+        cfg.merge_from_list(["MODEL.BATCH_SIZE", str(B), "MODEL.EPOCHS", str(epochs), "LOG.PERIOD", "1000",
+                             "MODEL.FD_OVERLAP_STEPS", os.environ.get("OVERLAP", "8")])
         cfg.freeze()
         d = tempfile.mkdtemp()
         lg = logging.getLogger("quiet%d_%d" % (B, epochs)); lg.setLevel(logging.ERROR)
