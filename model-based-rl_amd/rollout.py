@@ -81,6 +81,14 @@ class Linearisation:
                 e.fd_jacobians(Q[t0:t1].reshape(-1, e.nq), V[t0:t1].reshape(-1, e.nv), A[t0:t1].reshape(-1, e.nu),
                                eps=self.eps, fd_mode=self.fd_mode, out=out, policy=self.policy)
 
+    def __del__(self):
+        # the side stream reads buffers this object keeps alive (lin.keep): never let them return to the allocator
+        # while a launch that was submitted but not waited for (no backward pass) may still be running
+        try:
+            self.stream.synchronize()
+        except Exception:
+            pass
+
     def wait(self):
         """Make the current stream wait for everything submitted."""
         done = torch.cuda.Event()
