@@ -111,6 +111,13 @@ struct WaveMap {
 // unit MBRL_ST_BADPLAN and runs nothing.
 // The kernel gets the buffer as ONE pointer and derives the segments where it uses them (kernel arguments stay live in
 // scalar registers for the whole rollout, and those are short).
+// Waves are dispatched in grid order: walking the sorted units from the LARGEST key down starts the longest rollouts
+// first and leaves the short ones to fill the tail of the launch.
+#ifdef MBRL_PLAN_ASCENDING
+#define MBRL_PLAN_SLOT(slot) (slot)
+#else
+#define MBRL_PLAN_SLOT(slot) (N - 1 - (slot))
+#endif
 constexpr int kKeyBits = 62;   // (3 bits x the last 10 mj_forward calls) of Lean::key, then the same of Lean::key2
 constexpr int PLAN_NONE = 0, PLAN_WRITE = 1, PLAN_READ = 2;
 constexpr unsigned ST_BADPLAN = MBRL_ST_BADPLAN;
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_sk
         const int64_t slot = central ? g / (2 * NP) : g / NP;
         p = 1 + int(g - slot * (central ? 2 * NP : NP));
         live = slot < N;
-        unit = live ? int64_t(reinterpret_cast<const uint32_t *>(plan + PlanOffsets(N, NS).perm)[slot]) : 0;
+        unit = live ? int64_t(reinterpret_cast<const uint32_t *>(plan + PlanOffsets(N, NS).perm)[MBRL_PLAN_SLOT(slot)]) : 0;
         // a plan made for another batch holds arbitrary indices here: never follow one out of the arrays
         if (unit >= N) { live = false; unit = 0; }
         nom = 0; primary = true;
