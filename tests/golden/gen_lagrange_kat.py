@@ -13,7 +13,8 @@ differentiation in float64 (torch):
 The states float 5 m above the floor (no contact) and stay inside the joint ranges (no limit rows), so qacc is what
 mj_forward returns.  Body constants come from this script's own capsule formulas (MuJoCo 2.0 capsule volume
 pi r^2 (h + r), as in gen_sympy_kat.py) over the transcription in modelspec.py.
-Output: tests/golden/kat_lagrange.npz  (<env>_q, _v, _c, _qacc, _M).
+Output: tests/golden/kat_lagrange.npz  (<env>_q, _v, _c, _qacc, _M; for the RK4 model also _q1, _v1: the state after
+one mj_step, classic RK4 over the Lagrangian's own accelerations).
 """
 import math
 import os
@@ -128,7 +129,7 @@ def main():
         m = modelspec.MODELS[env]
         joints = [j for b in m["bodies"] for j in b["joints"]]
         nv, nu = len(joints), len(m["actuators"])
-        Q, V, C, A, MM = [], [], [], [], []
+        Q, V, C, A, MM, Q1, V1 = [], [], [], [], [], [], []
         for _ in range(12):
             q = np.zeros(nv)
             for i, j in enumerate(joints):
@@ -142,9 +143,20 @@ def main():
             c = rng.uniform(-1.2, 1.2, nu)                  # some beyond the control range: exercises the clamp
             a, Mq = qacc_of(m, q, v, c)
             Q.append(q); V.append(v); C.append(c); A.append(a); MM.append(Mq)
+            if m["integrator"] == "RK4":       # one mj_step: classic RK4 on (q, v) with dv/dt = qacc(q, v)
+                h = m["timestep"]
+                f = lambda qq, vv: (vv, qacc_of(m, qq, vv, c)[0])
+                k1q, k1v = f(q, v)
+                k2q, k2v = f(q + 0.5 * h * k1q, v + 0.5 * h * k1v)
+                k3q, k3v = f(q + 0.5 * h * k2q, v + 0.5 * h * k2v)
+                k4q, k4v = f(q + h * k3q, v + h * k3v)
+                Q1.append(q + h / 6 * (k1q + 2 * k2q + 2 * k3q + k4q))
+                V1.append(v + h / 6 * (k1v + 2 * k2v + 2 * k3v + k4v))
         pre = env[:-3].lower()
         out.update({pre + "_q": np.array(Q), pre + "_v": np.array(V), pre + "_c": np.array(C),
                     pre + "_qacc": np.array(A), pre + "_M": np.array(MM)})
+        if Q1:
+            out.update({pre + "_q1": np.array(Q1), pre + "_v1": np.array(V1)})
         print(env, "qacc range", np.abs(np.array(A)).max())
     np.savez(os.path.join(HERE, "kat_lagrange.npz"), **out)
 

@@ -84,6 +84,16 @@ def test_kernel_simulator_matches_lagrangian_trees(env, pre):
         assert np.abs(fs - f).max() <= 1e-12 * (1 + np.abs(f).max())
         if m["integrator"] == "RK4":
             assert np.abs(qa - a).max() <= 1e-12 * (1 + np.abs(a).max())
+            qn, vn, r = np.zeros((1, nv)), np.zeros((1, nv)), np.zeros(1)
+            st = np.zeros(1, dtype=np.uint32)
+            L.twin_step(i, 1, C.c_int64(1), q.ctypes.data_as(dp), v.ctypes.data_as(dp), c.ctypes.data_as(dp),
+                        qn.ctypes.data_as(dp), vn.ctypes.data_as(dp), r.ctypes.data_as(dp),
+                        st.ctypes.data_as(C.POINTER(C.c_uint32)))
+            k = [np.array_equal(q, x) for x in LAG[pre + "_q"]].index(True)
+            q1, v1 = LAG[pre + "_q1"][k], LAG[pre + "_v1"][k]        # classic RK4 over the Lagrangian's accelerations
+            assert st[0] == 0
+            assert np.abs(vn[0] - v1).max() <= 1e-11 * (1 + np.abs(v1).max())
+            assert np.abs(qn[0] - q1).max() <= 1e-12 * (1 + np.abs(q1).max())
         else:
             qn, vn, r = np.zeros((1, nv)), np.zeros((1, nv)), np.zeros(1)
             st = np.zeros(1, dtype=np.uint32)
@@ -94,3 +104,12 @@ def test_kernel_simulator_matches_lagrangian_trees(env, pre):
             assert st[0] == 0
             assert np.abs(vn[0] - v1).max() <= 1e-12 * (1 + np.abs(v1).max())
             assert np.abs(qn[0] - (q + h * v1)).max() <= 1e-13 * (1 + np.abs(q).max())
+
+
+def test_oracle_rk4_step_matches_lagrangian():
+    o = Oracle("Walker2dEnv")
+    q, v, c = LAG["walker2d_q"], LAG["walker2d_v"], LAG["walker2d_c"]
+    qn, vn, r, st = o.step(q, v, c, frame_skip=1)
+    assert not st.any()
+    assert np.abs(vn - LAG["walker2d_v1"]).max() <= 1e-11 * (1 + np.abs(LAG["walker2d_v1"]).max())
+    assert np.abs(qn - LAG["walker2d_q1"]).max() <= 1e-12 * (1 + np.abs(LAG["walker2d_q1"]).max())
