@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Known-answer vectors for the articulated planar trees (Hopper, Walker2d, HalfCheetah) in free flight.
+"""Known-answer vectors for the x-z planar models: the two cart-poles, and Hopper, Walker2d, HalfCheetah in free flight.
 
 A third formulation, independent of the oracle (3-D recursive spatial algebra) and of the kernel (planar
 composite-rigid-body recursion): the equations of motion from the Lagrangian.  Body poses P(q) = (x, z, angle) of
@@ -100,14 +100,15 @@ def qacc_of(m, q, v, c):
     arm = torch.tensor([j["armature"] for j in joints])
     kst = torch.tensor([j["stiffness"] for j in joints])
     dmp = torch.tensor([j["damping"] for j in joints])
-    mz = torch.tensor([w for (mass, _, _, _) in consts for w in (0.0, mass, 0.0)])
+    gx, gz = m["gravity"][0], m["gravity"][2]
+    mg = torch.tensor([w for (mass, _, _, _) in consts for w in (-mass * gx, -mass * gz, 0.0)])   # V = -sum m g.x
 
     def M_of(qq):
         J = torch.autograd.functional.jacobian(lambda x: poses(m, consts, x), qq, create_graph=True)
         return J.T @ (W[:, None] * J) + torch.diag(arm)
 
     def V_of(qq):
-        return G * (mz * poses(m, consts, qq)).sum() + 0.5 * (kst * qq * qq).sum()
+        return (mg * poses(m, consts, qq)).sum() + 0.5 * (kst * qq * qq).sum()
 
     q, v = torch.tensor(q), torch.tensor(v)
     Mq = M_of(q)
@@ -125,7 +126,7 @@ def qacc_of(m, q, v, c):
 def main():
     rng = np.random.default_rng(7)
     out = {}
-    for env in ("HopperEnv", "Walker2dEnv", "HalfCheetahEnv"):
+    for env in ("InvertedPendulumEnv", "InvertedDoublePendulumEnv", "HopperEnv", "Walker2dEnv", "HalfCheetahEnv"):
         m = modelspec.MODELS[env]
         joints = [j for b in m["bodies"] for j in b["joints"]]
         nv, nu = len(joints), len(m["actuators"])
@@ -138,7 +139,8 @@ def main():
                     q[i] = rng.uniform(lo + 0.15 * (hi - lo), hi - 0.15 * (hi - lo))
                 else:
                     q[i] = j["ref"] + rng.uniform(-0.5, 0.5)
-            q[1] += 5.0                                     # root z: far above the floor
+            if m["floor"]:
+                q[1] += 5.0                                 # root z: far above the floor
             v = rng.standard_normal(nv)
             c = rng.uniform(-1.2, 1.2, nu)                  # some beyond the control range: exercises the clamp
             a, Mq = qacc_of(m, q, v, c)

@@ -118,16 +118,18 @@ def test_saturated_controls_give_zero_action_columns(torch_cuda):
     assert float(out["drda"].abs().min()) > 0.0
 
 
-def test_step_kernel_rk4_matches_lagrangian_free_flight(torch_cuda):
-    """Walker2d (RK4): one mj_step of the HIP step kernel against classic RK4 over the Lagrangian's accelerations."""
+@pytest.mark.parametrize("env,pre", [("InvertedPendulumEnv", "invertedpendulum"),
+                                     ("InvertedDoublePendulumEnv", "inverteddoublependulum"), ("Walker2dEnv", "walker2d")])
+def test_step_kernel_rk4_matches_lagrangian(env, pre, torch_cuda):
+    """RK4 models: one mj_step of the HIP step kernel against classic RK4 over the Lagrangian's accelerations."""
     import os
     import mbrl_amd  # noqa: F401
     from mbrl_amd.engine import FdEngine
     G = np.load(os.path.join(os.path.dirname(__file__), "golden", "kat_lagrange.npz"))
-    e = FdEngine("Walker2dEnv", frame_skip=1)
-    qn, vn, r, st = e.step(G["walker2d_q"], G["walker2d_v"], G["walker2d_c"])
+    e = FdEngine(env, frame_skip=1)
+    qn, vn, r, st = e.step(G[pre + "_q"], G[pre + "_v"], G[pre + "_c"])
     assert int((st != 0).sum()) == 0
-    q1, v1 = G["walker2d_q1"], G["walker2d_v1"]
+    q1, v1 = G[pre + "_q1"], G[pre + "_v1"]
     assert np.abs(vn.cpu().numpy() - v1).max() <= 1e-11 * (1 + np.abs(v1).max())
     assert np.abs(qn.cpu().numpy() - q1).max() <= 1e-12 * (1 + np.abs(q1).max())
 

@@ -45,7 +45,9 @@ def test_kernel_simulator_qacc_matches_closed_form(env, pre):
 
 
 LAG = np.load(os.path.join(os.path.dirname(__file__), "golden", "kat_lagrange.npz"))
-TREES = (("HopperEnv", "hopper"), ("Walker2dEnv", "walker2d"), ("HalfCheetahEnv", "halfcheetah"))
+TREES = (("InvertedPendulumEnv", "invertedpendulum"), ("InvertedDoublePendulumEnv", "inverteddoublependulum"),
+         ("HopperEnv", "hopper"), ("Walker2dEnv", "walker2d"), ("HalfCheetahEnv", "halfcheetah"))
+RK4 = tuple(t for t in TREES if t[0] in ("InvertedPendulumEnv", "InvertedDoublePendulumEnv", "Walker2dEnv"))
 
 
 @pytest.mark.parametrize("env,pre", TREES)
@@ -106,10 +108,11 @@ def test_kernel_simulator_matches_lagrangian_trees(env, pre):
             assert np.abs(qn[0] - (q + h * v1)).max() <= 1e-13 * (1 + np.abs(q).max())
 
 
-def test_oracle_rk4_step_matches_lagrangian():
-    o = Oracle("Walker2dEnv")
-    q, v, c = LAG["walker2d_q"], LAG["walker2d_v"], LAG["walker2d_c"]
+@pytest.mark.parametrize("env,pre", RK4)
+def test_oracle_rk4_step_matches_lagrangian(env, pre):
+    o = Oracle(env)
+    q, v, c = LAG[pre + "_q"], LAG[pre + "_v"], LAG[pre + "_c"]
     qn, vn, r, st = o.step(q, v, c, frame_skip=1)
     assert not st.any()
-    assert np.abs(vn - LAG["walker2d_v1"]).max() <= 1e-11 * (1 + np.abs(LAG["walker2d_v1"]).max())
-    assert np.abs(qn - LAG["walker2d_q1"]).max() <= 1e-12 * (1 + np.abs(LAG["walker2d_q1"]).max())
+    assert np.abs(vn - LAG[pre + "_v1"]).max() <= 1e-11 * (1 + np.abs(LAG[pre + "_v1"]).max())
+    assert np.abs(qn - LAG[pre + "_q1"]).max() <= 1e-12 * (1 + np.abs(LAG[pre + "_q1"]).max())
