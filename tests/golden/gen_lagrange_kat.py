@@ -32,11 +32,19 @@ torch.set_default_dtype(torch.float64)
 G = 9.81
 
 
+U, W_, SENSE = 0, 2, 1.0     # in-plane coordinates (x, z), hinge sense about +y; set_plane() switches to (x, y), +z
+
+
+def set_plane(plane):
+    global U, W_, SENSE
+    U, W_, SENSE = (0, 2, 1.0) if plane == "xz" else (0, 1, -1.0)
+
+
 def capsule(a, b, r, rho):
     h = math.dist(a, b)
     mc, ms = rho * math.pi * r * r * h, rho * math.pi * r ** 3
     i_pe = mc * (3 * r * r + h * h) / 12 + ms * (2 * r * r / 5 + h * h / 4 + 3 * h * r / 8)
-    return mc + ms, i_pe, ((a[0] + b[0]) / 2, (a[2] + b[2]) / 2)
+    return mc + ms, i_pe, ((a[U] + b[U]) / 2, (a[W_] + b[W_]) / 2)
 
 
 def body_constants(m):
@@ -57,8 +65,8 @@ def body_constants(m):
 
 
 def rot(th, x, z):
-    """rotation about +y by th: +z turns towards +x"""
-    c, s = torch.cos(th), torch.sin(th)
+    """x-z plane: rotation about +y by th (+z turns towards +x); x-y plane: rotation about +z (+x turns towards +y)"""
+    c, s = torch.cos(th), SENSE * torch.sin(th)
     return c * x + s * z, -s * x + c * z
 
 
@@ -68,23 +76,23 @@ def poses(m, consts, q):
     for b, (mass, iyy, cx, cz) in zip(m["bodies"], consts):
         if b["parent"] < 0:
             ox, oz, th = torch.zeros(()), torch.zeros(()), torch.zeros(())
-            px, pz = b["pos"][0], b["pos"][2]
+            px, pz = b["pos"][U], b["pos"][W_]
         else:
             ox, oz, th = frames[b["parent"]]
-            px, pz = b["pos"][0], b["pos"][2]
+            px, pz = b["pos"][U], b["pos"][W_]
         dx, dz = rot(th, torch.tensor(px), torch.tensor(pz))
         ox, oz = ox + dx, oz + dz
         for j in b["joints"]:
             d = q[k] - j["ref"]
             k += 1
             if j["type"] == "slide":
-                ax, az = rot(th, torch.tensor(j["axis"][0]), torch.tensor(j["axis"][2]))
+                ax, az = rot(th, torch.tensor(j["axis"][U]), torch.tensor(j["axis"][W_]))
                 ox, oz = ox + d * ax, oz + d * az
             else:
-                ax_, az_ = rot(th, torch.tensor(j["pos"][0]), torch.tensor(j["pos"][2]))   # anchor, world offset
+                ax_, az_ = rot(th, torch.tensor(j["pos"][U]), torch.tensor(j["pos"][W_]))   # anchor, world offset
                 anx, anz = ox + ax_, oz + az_
-                th = th + d * j["axis"][1]
-                bx, bz = rot(th, torch.tensor(j["pos"][0]), torch.tensor(j["pos"][2]))
+                th = th + d * (j["axis"][1] if U + W_ == 2 else j["axis"][2])
+                bx, bz = rot(th, torch.tensor(j["pos"][U]), torch.tensor(j["pos"][W_]))
                 ox, oz = anx - bx, anz - bz
         frames.append((ox, oz, th))
         gx, gz = rot(th, torch.tensor(cx), torch.tensor(cz))
@@ -100,7 +108,7 @@ def qacc_of(m, q, v, c):
     arm = torch.tensor([j["armature"] for j in joints])
     kst = torch.tensor([j["stiffness"] for j in joints])
     dmp = torch.tensor([j["damping"] for j in joints])
-    gx, gz = m["gravity"][0], m["gravity"][2]
+    gx, gz = m["gravity"][U], m["gravity"][W_]
     mg = torch.tensor([w for (mass, _, _, _) in consts for w in (-mass * gx, -mass * gz, 0.0)])   # V = -sum m g.x
 
     def M_of(qq):
@@ -120,6 +128,7 @@ def qacc_of(m, q, v, c):
         if a["ctrllimited"]:
             u = min(max(u, a["ctrlrange"][0]), a["ctrlrange"][1])
         Q[names.index(a["joint"])] += a["gear"] * u
+    qacc_of.bias = (Cv + dV - kst * q).detach().numpy()        # Coriolis/centrifugal + gravity (MuJoCo's qfrc_bias)
     return torch.linalg.solve(Mq, Q - dV - Cv).detach().numpy(), Mq.detach().numpy()
 
 
@@ -128,6 +137,7 @@ def main():
     out = {}
     for env in ("InvertedPendulumEnv", "InvertedDoublePendulumEnv", "HopperEnv", "Walker2dEnv", "HalfCheetahEnv"):
         m = modelspec.MODELS[env]
+        set_plane(m["plane"])
         joints = [j for b in m["bodies"] for j in b["joints"]]
         nv, nu = len(joints), len(m["actuators"])
         Q, V, C, A, MM, Q1, V1 = [], [], [], [], [], [], []
@@ -160,6 +170,19 @@ def main():
         if Q1:
             out.update({pre + "_q1": np.array(Q1), pre + "_v1": np.array(V1)})
         print(env, "qacc range", np.abs(np.array(A)).max())
+    # Swimmer (x-y plane, hinges about +z): its fluid forces are MuJoCo's own model, outside a Lagrangian, so only the
+    # mass matrix and the Coriolis/centrifugal bias are recorded (gravity is normal to the plane)
+    m = modelspec.MODELS["SwimmerEnv"]
+    set_plane(m["plane"])
+    joints = [j for b in m["bodies"] for j in b["joints"]]
+    Q, V, MM, BB = [], [], [], []
+    for _ in range(12):
+        q = np.array([rng.uniform(-0.5, 0.5) if not j["limited"] else
+                      rng.uniform(j["range"][0] * 0.8, j["range"][1] * 0.8) for j in joints])
+        v = rng.standard_normal(len(joints))
+        _, Mq = qacc_of(m, q, v, np.zeros(len(m["actuators"])))
+        Q.append(q); V.append(v); MM.append(Mq); BB.append(qacc_of.bias)
+    out.update(swimmer_q=np.array(Q), swimmer_v=np.array(V), swimmer_M=np.array(MM), swimmer_bias=np.array(BB))
     np.savez(os.path.join(HERE, "kat_lagrange.npz"), **out)
 
 

@@ -116,3 +116,14 @@ def test_oracle_rk4_step_matches_lagrangian(env, pre):
     assert not st.any()
     assert np.abs(vn - LAG[pre + "_v1"]).max() <= 1e-11 * (1 + np.abs(LAG[pre + "_v1"]).max())
     assert np.abs(qn - LAG[pre + "_q1"]).max() <= 1e-12 * (1 + np.abs(LAG[pre + "_q1"]).max())
+
+
+def test_oracle_swimmer_mass_matrix_and_bias_match_lagrangian():
+    """Swimmer (x-y plane, hinges about +z): mass matrix and Coriolis/centrifugal bias; its fluid forces are MuJoCo's own
+    model and stay outside this pin."""
+    o = Oracle("SwimmerEnv")
+    for q, v, M, b in zip(LAG["swimmer_q"], LAG["swimmer_v"], LAG["swimmer_M"], LAG["swimmer_bias"]):
+        f = o.forward(q, v, np.zeros(2))
+        Mo = np.tril(f["M"]) + np.tril(f["M"], -1).T
+        assert np.abs(Mo - M).max() <= 1e-13 * np.abs(M).max()
+        assert np.abs(f["qfrc_bias"] - b).max() <= 1e-12 * (1 + np.abs(b).max())
