@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MBRL_ABI_VERSION 4
+#define MBRL_ABI_VERSION 5
 
 /* per-unit status bits (replace mujoco-py's MujocoException / the reference's asserts,
  * backward.py:371,374) */
@@ -107,6 +107,22 @@ int mbrl_fd_jacobians_planned(const mbrl_model *m, int64_t N, const double *qpos
                               const double *ctrl_pert, double eps, int fd_mode, int nsteps, const void *plan,
                               int64_t plan_bytes, double *dsds, double *dsda, double *drds, double *drda,
                               uint32_t *status, void *hip_stream);
+
+/* NO COUNTERPART IN THE REFERENCE.  For callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc) and so cannot bring the plan workspace mbrl_fd_plan wants: the same
+ * two-launch linearisation (mbrl_fd_plan then mbrl_fd_jacobians_planned, open loop), with the plan held in a static
+ * device array inside the library -- MBRL_STATIC_SCRATCH_BYTES per GPU, held until the process ends; its device
+ * address is looked up once per device in mbrl_model_create.  Inputs and outputs are the caller's, exactly as in
+ * mbrl_fd_jacobians, and so are the results, bit for bit.  The call itself allocates nothing (no hipMalloc / hipFree,
+ * no allocating library routine).  N > MBRL_STATIC_MAX_UNITS (or a plan beyond the array) is rejected with -8.
+ * Every call on a GPU uses that GPU's one array: calls that overlap on one GPU (two streams, two threads) RACE --
+ * serialise them, or use the caller-owned plan buffers of mbrl_fd_plan.  Nothing in the array needs clearing between
+ * calls (each call rewrites the header, keys, order and nominal results of its own N units before reading them). */
+#define MBRL_STATIC_MAX_UNITS 32768
+#define MBRL_STATIC_SCRATCH_BYTES (8u << 20)
+int mbrl_fd_jacobians_static(const mbrl_model *m, int64_t N, const double *qpos, const double *qvel, const double *ctrl,
+                             double eps, int fd_mode, int nsteps, double *dsds, double *dsda, double *drds, double *drda,
+                             double *s_next, double *reward, uint32_t *status, void *hip_stream);
 
 /* Replaces the chain of MjBlock.backward calls that autograd issues for one epoch
  * (model/blocks/mujoco.py:43-104; recurrence in SURVEY.md App. C): for each of B

@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "../../include/mbrl.h"
@@ -379,6 +380,34 @@ static int fail(int code, const char *fmt, const char *a = "", long long b = 0) 
     default: break;                                                    \
     }
 
+// ---- scratch of the no-allocation entry point (mbrl_fd_jacobians_static) ----
+// The launch plan of the two-launch schedule (PlanOffsets + sort scratch) normally lives in a caller-supplied workspace.
+// Callers that cannot allocate get it here: a file-scope device array, one copy per GPU, held until the process ends.
+// `scratch` is only a host-side stand-in for the symbol; host code never passes it anywhere.  Its device address is
+// looked up once per device (scratch_init, with that device current) and kept in g_scratch_ptr, and that pointer is
+// what every kernel argument / memset / copy uses.
+constexpr size_t kStaticScratchBytes = size_t(MBRL_STATIC_SCRATCH_BYTES);
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+constexpr int kMaxDevices = 64;
+static void *g_scratch_ptr[kMaxDevices] = {};
+static std::mutex g_scratch_mu;
+
+// Once per device, at set-up (mbrl_model_create): the address of THIS device's copy of `scratch`.
+static int scratch_init(int device) {
+    if (device < 0 || device >= kMaxDevices) return -1;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr[device]) return 0;
+    int prev = 0;
+    if (hipGetDevice(&prev) != hipSuccess) return -1;
+    if (hipSetDevice(device) != hipSuccess) return -1;
+    void *ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess || !ptr) return -1;
+    g_scratch_ptr[device] = ptr;
+    return 0;
+}
+
 static const char *kEnvNames[] = {"InvertedPendulumEnv", "InvertedDoublePendulumEnv", "SwimmerEnv",
                                   "HopperEnv", "Walker2dEnv", "HalfCheetahEnv"};
 
@@ -482,6 +511,8 @@ int mbrl_model_create(const char *env_name, int frame_skip, int device, mbrl_mod
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(-3, "mbrl_model_create: no HIP device visible (this library has no CPU path)");
     if (device < 0 || device >= ndev) return fail(-4, "mbrl_model_create: bad device ordinal %s%lld", "", device);
+    if (device < kMaxDevices && scratch_init(device))
+        return fail(-10, "mbrl_model_create: hipGetSymbolAddress(scratch) failed on device %s%lld", "", device);
     mbrl_model *m = new (std::nothrow) mbrl_model();
     if (!m) return fail(-5, "mbrl_model_create: out of host memory");
     m->env_id = id; m->frame_skip = frame_skip; m->device = device;
@@ -618,6 +649,31 @@ int mbrl_fd_jacobians_planned(const mbrl_model *m, int64_t N, const double *qpos
                                            status, st, static_cast<char *>(const_cast<void *>(plan)), PLAN_READ)));
     if (rc) return fail(-6, "mbrl_fd_jacobians_planned: N too large for one launch");
     return check_launch(m, "mbrl_fd_jacobians_planned");
+}
+
+int mbrl_fd_jacobians_static(const mbrl_model *m, int64_t N, const double *qpos, const double *qvel, const double *ctrl,
+                             double eps, int fd_mode, int nsteps, double *dsds, double *dsda, double *drds, double *drda,
+                             double *s_next, double *reward, uint32_t *status, void *hip_stream) {
+    if (!m) return fail(-1, "mbrl_fd_jacobians_static: null model");
+    if (N < 0) return fail(-6, "mbrl_fd_jacobians_static: negative N");
+    if (N == 0) return 0;
+    if (N > int64_t(MBRL_STATIC_MAX_UNITS))
+        return fail(-8, "mbrl_fd_jacobians_static: N exceeds MBRL_STATIC_MAX_UNITS%s (%lld units asked; use mbrl_fd_plan + "
+                        "mbrl_fd_jacobians_planned with a caller-owned plan buffer)", "", (long long)N);
+    void *ptr = (m->device >= 0 && m->device < kMaxDevices) ? g_scratch_ptr[m->device] : nullptr;
+    if (!ptr) return fail(-10, "mbrl_fd_jacobians_static: no static scratch on this device");
+    if (hipSetDevice(m->device) != hipSuccess) return fail(-4, "mbrl_fd_jacobians_static: hipSetDevice failed");
+    PlanLayout L;
+    if (!plan_layout(N, m->nq + m->nv, (hipStream_t)hip_stream, L))
+        return fail(-10, "mbrl_fd_jacobians_static: sort size query failed");
+    if (L.total > kStaticScratchBytes)
+        return fail(-8, "mbrl_fd_jacobians_static: the plan of this batch does not fit the static scratch%s (%lld bytes)", "",
+                    (long long)L.total);
+    // both launches take the device address looked up at set-up, never the symbol's name
+    int rc = mbrl_fd_plan(m, N, qpos, qvel, ctrl, nsteps, ptr, int64_t(kStaticScratchBytes), s_next, reward, status, hip_stream);
+    if (rc) return rc;
+    return mbrl_fd_jacobians_planned(m, N, qpos, qvel, ctrl, nullptr, eps, fd_mode, nsteps, ptr, int64_t(kStaticScratchBytes),
+                                     dsds, dsda, drds, drda, status, hip_stream);
 }
 
 int mbrl_vjp_scan(const mbrl_model *m, int64_t B, int H, int grad_weights, const double *dsds, const double *dsda,

@@ -11,11 +11,12 @@ LIB_PATH = os.environ.get("MBRL_LIB") or os.path.join(HERE, "csrc", "libmbrl_hip
 
 ST_NONFINITE, ST_NOCONVERGE, ST_OVERFLOW, ST_DEGENERATE, ST_BADPLAN = 1, 2, 4, 8, 16
 FD_FORWARD, FD_CENTRAL = 0, 1
+STATIC_MAX_UNITS = 32768
 EPISODE_MAJOR, TIME_MAJOR = 0, 1
 
 SYMBOLS = ("mbrl_abi_version", "mbrl_model_create", "mbrl_model_destroy", "mbrl_model_dims", "mbrl_step",
            "mbrl_fd_jacobians", "mbrl_fd_jacobians_closed_loop", "mbrl_fd_plan_bytes", "mbrl_fd_plan",
-           "mbrl_fd_jacobians_planned", "mbrl_vjp_scan", "mbrl_vjp_scan_layout", "mbrl_lane_map", "mbrl_last_error")
+           "mbrl_fd_jacobians_planned", "mbrl_fd_jacobians_static", "mbrl_vjp_scan", "mbrl_vjp_scan_layout", "mbrl_lane_map", "mbrl_last_error")
 
 _lib = None
 vp = C.c_void_p
@@ -51,9 +52,10 @@ def load():
     L.mbrl_fd_plan.argtypes = [vp, C.c_int64, vp, vp, vp, C.c_int, vp, C.c_int64, vp, vp, vp, vp]
     L.mbrl_fd_jacobians_planned.argtypes = [vp, C.c_int64, vp, vp, vp, vp, C.c_double, C.c_int, C.c_int, vp, C.c_int64] + \
                                            [vp] * 5 + [vp]
+    L.mbrl_fd_jacobians_static.argtypes = L.mbrl_fd_jacobians.argtypes
     L.mbrl_vjp_scan.argtypes = [vp, C.c_int64, C.c_int, C.c_int] + [vp] * 7 + [vp]
     L.mbrl_vjp_scan_layout.argtypes = [vp, C.c_int64, C.c_int, C.c_int, C.c_int] + [vp] * 7 + [vp]
-    if L.mbrl_abi_version() != 4:
+    if L.mbrl_abi_version() != 5:
         raise MbrlError("ABI version mismatch")
     _lib = L
     return L
