@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MBRL_ABI_VERSION 5
+#define MBRL_ABI_VERSION 6
 
 /* per-unit status bits (replace mujoco-py's MujocoException / the reference's asserts,
  * backward.py:371,374) */
@@ -145,6 +145,15 @@ int mbrl_vjp_scan(const mbrl_model *m, int64_t B, int H, int grad_weights, const
 int mbrl_vjp_scan_layout(const mbrl_model *m, int64_t B, int H, int grad_weights, int layout, const double *dsds,
                          const double *dsda, const double *drds, const double *drda, const double *c, double *da,
                          double *ds0, void *hip_stream);
+
+/* The same for ONE SHARD of a batch that is split over several GPUs (one process each; the reference is single-process,
+ * model/engine/trainer.py:57-77): the B episodes of this call are episodes [episode_offset, episode_offset + B) of
+ * total_episodes.  Only 'prioritise' depends on it -- its running sum carries over from episode to episode in the order
+ * autograd visits them (last to first, model/blocks/mujoco.py:65), so a shard starts from what the later episodes of
+ * the WHOLE batch have added; with (0, B) this is mbrl_vjp_scan_layout.  No communication: every rank computes its seed. */
+int mbrl_vjp_scan_sharded(const mbrl_model *m, int64_t B, int H, int grad_weights, int layout, int64_t episode_offset,
+                          int64_t total_episodes, const double *dsds, const double *dsda, const double *drds,
+                          const double *drda, const double *c, double *da, double *ds0, void *hip_stream);
 
 /* Introspection (host only, no GPU call; no counterpart in the reference): how the rollouts of a launch are laid
  * out over the 2 x 64 lanes of a wave pair for a model with the given dimensions.  fd_mode: MBRL_FD_FORWARD, MBRL_FD_CENTRAL, or -1 for

@@ -75,8 +75,11 @@ class DataSnapshot:
 
 
 class Agent:
-    def __init__(self, cfg, batch=1, device=None, engine=None):
+    def __init__(self, cfg, batch=1, device=None, engine=None, shard=None):
+        """shard = (first episode, episodes of the whole batch) when this agent advances one rank's block of a batch
+        that is split over several GPUs; default: the agent owns the whole batch."""
         self.cfg = cfg
+        self.episode_offset, self.total_batch = (int(shard[0]), int(shard[1])) if shard else (0, int(batch))
         env = cfg.MUJOCO.ENV
         self.engine = engine or FdEngine(env, frame_skip=cfg.MODEL.FRAME_SKIP, device=device)
         e = self.engine
@@ -152,15 +155,18 @@ class Agent:
         q = self.init_qpos.repeat(B, 1)
         v = self.init_qvel.repeat(B, 1)
         if self.cfg.MODEL.POLICY.NETWORK and env in ("HalfCheetahEnv", "HopperEnv", "SwimmerEnv"):
-            r = self.np_random
+            # Reset noise is drawn for the WHOLE batch from the (identically seeded) generator and sliced, so that a
+            # rank of a sharded run starts its episodes where a single-process run starts the same episodes.
+            r, T = self.np_random, self.total_batch
             if env == "HalfCheetahEnv":      # half_cheetah.py:45-48
-                dq, dv = r.uniform(-.1, .1, (B, e.nq)), r.standard_normal((B, e.nv)) * .1
+                dq, dv = r.uniform(-.1, .1, (T, e.nq)), r.standard_normal((T, e.nv)) * .1
             elif env == "HopperEnv":         # hopper.py:58-59
-                dq, dv = r.uniform(-.005, .005, (B, e.nq)), r.uniform(-.005, .005, (B, e.nv))
+                dq, dv = r.uniform(-.005, .005, (T, e.nq)), r.uniform(-.005, .005, (T, e.nv))
             else:                            # swimmer.py:44-45
-                dq, dv = r.uniform(-.1, .1, (B, e.nq)), r.uniform(-.1, .1, (B, e.nv))
-            q = q + torch.as_tensor(dq, device=e.device)
-            v = v + torch.as_tensor(dv, device=e.device)
+                dq, dv = r.uniform(-.1, .1, (T, e.nq)), r.uniform(-.1, .1, (T, e.nv))
+            sl = slice(self.episode_offset, self.episode_offset + B)
+            q = q + torch.as_tensor(dq[sl], device=e.device)
+            v = v + torch.as_tensor(dv[sl], device=e.device)
         if env == "InvertedPendulumEnv":     # inverted_pendulum.py:44
             q, v = torch.zeros_like(q), torch.zeros_like(v)
         self.data.qpos[:], self.data.qvel[:] = q, v
@@ -225,8 +231,9 @@ class Agent:
         return mj_gradients
 
 
-def build_agent(cfg, batch=1, device=None):
-    """Reference: mujoco/build.py:6-37 (viewer/video wrappers are out of scope)."""
+def build_agent(cfg, batch=1, device=None, engine=None, shard=None):
+    """Reference: mujoco/build.py:6-37 (viewer/video wrappers are out of scope).  `engine`: an object with FdEngine's
+    interface to use instead of creating one (the multi-process CPU tests pass a stand-in); `shard`: see Agent."""
     if cfg.MUJOCO.ENV not in modelspec.MODELS:
         raise AttributeError("module 'envs' has no attribute %r" % (cfg.MUJOCO.ENV,))
-    return Agent(cfg, batch=batch, device=device)
+    return Agent(cfg, batch=batch, device=device, engine=engine, shard=shard)

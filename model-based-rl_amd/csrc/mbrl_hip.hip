@@ -311,7 +311,9 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_sk
 // Backward recurrence of the op chain (mujoco.py:43-104): one thread per (episode, output lane).
 // n <= 18, nu <= 6: each episode is walked by one 32-lane group; lane l owns g[l].
 // Unit (b, t) sits at index b * sb + t * st of every array: episode-major (sb = H, st = 1) or time-major (sb = 1, st = B).
+// Episode b of this launch is episode b_off + b of a batch of b_tot (a rank's shard of a sharded batch; 0, B otherwise).
 __global__ __launch_bounds__(kBlock) void vjp_scan_kernel(int64_t B, int H, int n, int nu, int gw, int64_t sb, int64_t st,
+                                                           int64_t b_off, int64_t b_tot,
                                                            const double *__restrict__ dsds,
                                                            const double *__restrict__ dsda,
                                                            const double *__restrict__ drds,
@@ -323,8 +325,9 @@ __global__ __launch_bounds__(kBlock) void vjp_scan_kernel(int64_t B, int H, int 
     const int64_t b = int64_t(blockIdx.x) * (kBlock / 32) + grp;
     const bool live = b < B;
     double g = 0.0;  // g_{t+1}[l]
-    // 'prioritise': autograd runs episodes last-to-first, the running sum carries over (mujoco.py:65)
-    double S = live ? double(B - 1 - b) * (0.5 * double(H) * double(H + 1)) : 0.0;
+    // 'prioritise': autograd runs episodes last-to-first, the running sum carries over (mujoco.py:65) -- over the
+    // episodes of the WHOLE batch, so a shard seeds it with what the later episodes of every rank have added
+    double S = live ? double(b_tot - 1 - (b_off + b)) * (0.5 * double(H) * double(H + 1)) : 0.0;
     for (int t = H - 1; t >= 0; t--) {
         gs[grp][l] = g;
         __syncthreads();
@@ -684,7 +687,15 @@ int mbrl_vjp_scan(const mbrl_model *m, int64_t B, int H, int grad_weights, const
 int mbrl_vjp_scan_layout(const mbrl_model *m, int64_t B, int H, int grad_weights, int layout, const double *dsds,
                          const double *dsda, const double *drds, const double *drda, const double *c, double *da,
                          double *ds0, void *hip_stream) {
+    return mbrl_vjp_scan_sharded(m, B, H, grad_weights, layout, 0, B, dsds, dsda, drds, drda, c, da, ds0, hip_stream);
+}
+
+int mbrl_vjp_scan_sharded(const mbrl_model *m, int64_t B, int H, int grad_weights, int layout, int64_t episode_offset,
+                          int64_t total_episodes, const double *dsds, const double *dsda, const double *drds,
+                          const double *drda, const double *c, double *da, double *ds0, void *hip_stream) {
     if (!m) return fail(-1, "mbrl_vjp_scan: null model");
+    if (episode_offset < 0 || total_episodes < episode_offset + B)
+        return fail(-6, "mbrl_vjp_scan_sharded: the shard [offset, offset + B) must lie inside [0, total_episodes)");
     if (layout != MBRL_EPISODE_MAJOR && layout != MBRL_TIME_MAJOR) return fail(-7, "mbrl_vjp_scan: bad layout");
     if (B < 0 || H < 0) return fail(-6, "mbrl_vjp_scan: negative size");
     if (B == 0 || H == 0) return 0;
@@ -695,7 +706,7 @@ int mbrl_vjp_scan_layout(const mbrl_model *m, int64_t B, int H, int grad_weights
     const unsigned blocks = (unsigned)((B + per - 1) / per);
     const int64_t sb = layout == MBRL_TIME_MAJOR ? 1 : H, st = layout == MBRL_TIME_MAJOR ? B : 1;
     hipLaunchKernelGGL(vjp_scan_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)hip_stream, B, H, m->nq + m->nv,
-                       m->nu, grad_weights, sb, st, dsds, dsda, drds, drda, c, da, ds0);
+                       m->nu, grad_weights, sb, st, episode_offset, total_episodes, dsds, dsda, drds, drda, c, da, ds0);
     return check_launch(m, "mbrl_vjp_scan");
 }
 

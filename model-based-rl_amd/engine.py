@@ -14,6 +14,21 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+class Plan:
+    """Launch-plan workspace of the two-launch linearisation (include/mbrl.h: mbrl_fd_plan): a grow-only device buffer
+    and the batch size its current plan was made for."""
+
+    def __init__(self):
+        self.buf, self.units = None, -1
+
+    def reserve(self, engine, N):
+        need = engine.plan_bytes(N)
+        if self.buf is None or self.buf.numel() < need:
+            self.buf = torch.empty(need, dtype=torch.uint8, device=engine.device)   # torch blocks are 512-byte aligned
+            self.units = -1
+        return self.buf
+
+
 class FdEngine:
     """One immutable model handle on one GPU (reference: build_agent, mujoco/build.py:6-37)."""
 
@@ -31,8 +46,8 @@ class FdEngine:
         lib.check(self.L.mbrl_model_dims(h, nq, nv, nu, dt))
         self.env, self.nq, self.nv, self.nu, self.dt = env, nq.value, nv.value, nu.value, dt.value
         self.n = self.nq + self.nv
-        self._plan = None                      # grow-only launch-plan buffer (mbrl_fd_plan), owned by this engine
-        self._plan_units = -1                  # batch size the buffer's current plan was made for
+        self._plans = {}                       # HIP stream -> Plan: one grow-only launch-plan buffer per stream that
+                                               # linearises through this engine (streams never share a plan)
         self._schedule = {}                    # (mode, nsteps, closed loop, size class) -> planned schedule is faster
 
     def __del__(self):
@@ -116,13 +131,35 @@ class FdEngine:
             a = fn(P.reshape(-1, n)).double()
         return a.reshape(P.shape[:-1] + (self.nu,)).contiguous()
 
-    def _plan_buffer(self, N):
+    def plan_bytes(self, N):
         need = int(self.L.mbrl_fd_plan_bytes(self.h, N))
         if need < 0:
             lib.check(need)
-        if self._plan is None or self._plan.numel() < need:
-            self._plan = torch.empty(need, dtype=torch.uint8, device=self.device)   # torch blocks are 512-byte aligned
-        return self._plan
+        return need
+
+    def new_plan(self, N=0):
+        """A caller-owned launch plan (workspace of mbrl_fd_plan / mbrl_fd_jacobians_planned) for batches of up to N
+        units; it grows on demand.  Pass it as `plan=` to fd_plan / fd_planned / fd_jacobians.  Callers that linearise
+        on several streams at once use one Plan per stream (the default, plan=None, does exactly that)."""
+        p = Plan()
+        if N:
+            p.reserve(self, N)
+        return p
+
+    def _stream_plan(self):
+        """The plan that belongs to the CURRENT stream.  Its buffer is allocated while that stream is current, so the
+        caching allocator ties the block to it: a regrown buffer's old block is not handed out again before the
+        launches already queued on the stream have run."""
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        p = self._plans.get(key)
+        if p is None:
+            p = self._plans[key] = Plan()
+        return p
+
+    @property
+    def _plan(self):
+        """Buffer of the current stream's plan (tests look inside it)."""
+        return self._stream_plan().buf
 
     def _fd_args(self, qpos, qvel, ctrl, eps, fd_mode, policy, ctrl_pert):
         qpos, qvel, ctrl = self._in(qpos, self.nq), self._in(qvel, self.nv), self._in(ctrl, self.nu)
@@ -143,36 +180,45 @@ class FdEngine:
         return dict(dsds=self._new(N, n, n), dsda=self._new(N, n, nu), drds=self._new(N, n), drda=self._new(N, nu),
                     s_next=self._new(N, n), reward=self._new(N), status=self._new(N, dtype=torch.int32))
 
-    def fd_plan(self, qpos, qvel, ctrl, nsteps=1, out=None):
+    def fd_plan(self, qpos, qvel, ctrl, nsteps=1, out=None, plan=None):
         """First launch of the two-launch linearisation (mbrl_fd_plan): the nominal rollouts (-> out s_next, reward,
-        status) and the order in which mbrl_fd_jacobians_planned walks the units.  The plan lives in this engine's
-        buffer until the next fd_plan call."""
+        status) and the order in which mbrl_fd_jacobians_planned walks the units.  The plan lives in `plan` (default:
+        the current stream's own plan) until the next fd_plan call on it."""
         qpos, qvel, ctrl, _ = self._fd_args(qpos, qvel, ctrl, 0.0, lib.FD_FORWARD, None, None)
         N = qpos.shape[0]
         o = out or self.new_outputs(N)
         if N:
-            plan = self._plan_buffer(N)
-            self._plan_units = N
+            plan = plan or self._stream_plan()
+            buf = plan.reserve(self, N)
+            plan.units = N
             with torch.cuda.device(self.device):
-                lib.check(self.L.mbrl_fd_plan(self.h, N, _ptr(qpos), _ptr(qvel), _ptr(ctrl), int(nsteps), _ptr(plan),
-                                              plan.numel(), _ptr(o["s_next"]), _ptr(o["reward"]), _ptr(o["status"]),
-                                              self._stream()))
+                lib.check(self.L.mbrl_fd_plan(self.h, N, _ptr(qpos), _ptr(qvel), _ptr(ctrl), int(nsteps), _ptr(buf),
+                                              buf.numel(), _ptr(o.get("s_next")), _ptr(o.get("reward")),
+                                              _ptr(o.get("status")), self._stream()))
         return o
 
-    def fd_planned(self, qpos, qvel, ctrl, out, eps=1e-6, fd_mode=lib.FD_FORWARD, nsteps=1, policy=None, ctrl_pert=None):
+    def fd_planned(self, qpos, qvel, ctrl, out, eps=1e-6, fd_mode=lib.FD_FORWARD, nsteps=1, policy=None, ctrl_pert=None,
+                   plan=None):
         """Second launch (mbrl_fd_jacobians_planned): the perturbed rollouts of the units fd_plan saw, in its order."""
         qpos, qvel, ctrl, ctrl_pert = self._fd_args(qpos, qvel, ctrl, eps, fd_mode, policy, ctrl_pert)
         N = qpos.shape[0]
         if N:
-            plan = self._plan
-            if plan is None or self._plan_units != N:
+            plan = plan or self._stream_plan()
+            if plan.buf is None or plan.units != N:
                 raise lib.MbrlError("fd_planned: no plan for a batch of %d units (call fd_plan on the same inputs first)" % N)
             with torch.cuda.device(self.device):
                 lib.check(self.L.mbrl_fd_jacobians_planned(
                     self.h, N, _ptr(qpos), _ptr(qvel), _ptr(ctrl), _ptr(ctrl_pert), float(eps), int(fd_mode), int(nsteps),
-                    _ptr(plan), plan.numel(), _ptr(out["dsds"]), _ptr(out["dsda"]), _ptr(out["drds"]), _ptr(out["drda"]),
-                    _ptr(out["status"]), self._stream()))
+                    _ptr(plan.buf), plan.buf.numel(), _ptr(out["dsds"]), _ptr(out["dsda"]), _ptr(out["drds"]),
+                    _ptr(out["drda"]), _ptr(out["status"]), self._stream()))
         return out
+
+    def schedule_key(self, N, fd_mode, nsteps, closed_loop):
+        return (int(fd_mode), int(nsteps), bool(closed_loop), max(int(N), 1).bit_length())
+
+    def known_schedule(self, N, fd_mode=lib.FD_FORWARD, nsteps=1, closed_loop=False):
+        """True / False once tune_schedule has measured this size class, None before."""
+        return self._schedule.get(self.schedule_key(N, fd_mode, nsteps, closed_loop))
 
     def _faster_schedule(self, qpos, qvel, ctrl, ctrl_pert, eps, fd_mode, nsteps, o):
         """Which of the two schedules is faster for this model, mode and batch size?  They produce the same bits, so
@@ -180,7 +226,7 @@ class FdEngine:
         The plan pays off when the linearisation is long against one latency-bound launch of nominal rollouts:
         HalfCheetah from ~3e4 units (forward) -- not for the pendulums, nor for small batches."""
         N = qpos.shape[0]
-        key = (int(fd_mode), int(nsteps), ctrl_pert is not None, max(N, 1).bit_length())
+        key = self.schedule_key(N, fd_mode, nsteps, ctrl_pert is not None)
         if key not in self._schedule:
             ms = {}
             for planned in (False, True):
@@ -195,19 +241,31 @@ class FdEngine:
             self._schedule[key] = ms[True] < ms[False]
         return self._schedule[key]
 
+    def tune_schedule(self, qpos, qvel, ctrl, eps=1e-6, fd_mode=lib.FD_FORWARD, nsteps=1, policy=None, ctrl_pert=None):
+        """Measure both schedules once for this size class on the CURRENT stream (host-blocking: call it at warm-up,
+        never from a stream that is meant to run beside another one) and remember the faster."""
+        qpos, qvel, ctrl, ctrl_pert = self._fd_args(qpos, qvel, ctrl, eps, fd_mode, policy, ctrl_pert)
+        N = qpos.shape[0]
+        if N < 1024:
+            return False
+        return self._faster_schedule(qpos, qvel, ctrl, ctrl_pert, eps, fd_mode, nsteps, self.new_outputs(N))
+
     def fd_jacobians(self, qpos, qvel, ctrl, eps=1e-6, fd_mode=lib.FD_FORWARD, nsteps=1, out=None, policy=None,
-                     ctrl_pert=None, planned=None):
+                     ctrl_pert=None, planned=None, plan=None):
         """calculate_gradients for N units (backward.py:343-480).  planned=True: mbrl_fd_plan then
         mbrl_fd_jacobians_planned; planned=False: the single launch mbrl_fd_jacobians_closed_loop; None (default): the
-        faster of the two for this model / mode / batch size (measured once, see _faster_schedule).  Same bits."""
+        faster of the two for this model / mode / batch size (measured once per size class, see tune_schedule;
+        "cached": use the remembered choice, single launch when there is none -- never measures).  Same bits."""
         qpos, qvel, ctrl, ctrl_pert = self._fd_args(qpos, qvel, ctrl, eps, fd_mode, policy, ctrl_pert)
         N = qpos.shape[0]
         o = out or self.new_outputs(N)
-        if planned is None:
+        if planned == "cached":
+            planned = bool(self.known_schedule(N, fd_mode, nsteps, ctrl_pert is not None))
+        elif planned is None:
             planned = N >= 1024 and self._faster_schedule(qpos, qvel, ctrl, ctrl_pert, eps, fd_mode, nsteps, o)
         if planned:
-            self.fd_plan(qpos, qvel, ctrl, nsteps, o)
-            return self.fd_planned(qpos, qvel, ctrl, o, eps, fd_mode, nsteps, ctrl_pert=ctrl_pert)
+            self.fd_plan(qpos, qvel, ctrl, nsteps, o, plan=plan)
+            return self.fd_planned(qpos, qvel, ctrl, o, eps, fd_mode, nsteps, ctrl_pert=ctrl_pert, plan=plan)
         with torch.cuda.device(self.device):
             lib.check(self.L.mbrl_fd_jacobians_closed_loop(
                 self.h, N, _ptr(qpos), _ptr(qvel), _ptr(ctrl), _ptr(ctrl_pert), float(eps), int(fd_mode), int(nsteps),
@@ -215,16 +273,19 @@ class FdEngine:
                 _ptr(o["reward"]), _ptr(o["status"]), self._stream()))
         return o
 
-    def vjp_scan(self, jac, c, grad_weights="average", time_major=False):
+    def vjp_scan(self, jac, c, grad_weights="average", time_major=False, shard=None):
         """Backward recurrence over the stored Jacobians.  Episode-major (default): c = dL/dreward [B, H], unit (b, t) at
-        b*H + t, returns da [B, H, nu].  time_major: c [H, B], unit at t*B + b, returns da [H, B, nu].  ds0 [B, n]."""
+        b*H + t, returns da [B, H, nu].  time_major: c [H, B], unit at t*B + b, returns da [H, B, nu].  ds0 [B, n].
+        shard = (episode_offset, total_episodes) when these B episodes are one rank's block of a larger batch."""
         gw = {"none": 0, "average": 1, "prioritise": 2}.get(grad_weights, 0)
         c = torch.as_tensor(c, dtype=torch.float64, device=self.device).contiguous()
         B, H = (c.shape[1], c.shape[0]) if time_major else c.shape
         da = self._new(H, B, self.nu) if time_major else self._new(B, H, self.nu)
         ds0 = self._new(B, self.n)
         with torch.cuda.device(self.device):
-            lib.check(self.L.mbrl_vjp_scan_layout(self.h, B, H, gw, lib.TIME_MAJOR if time_major else lib.EPISODE_MAJOR,
-                                                  _ptr(jac["dsds"]), _ptr(jac["dsda"]), _ptr(jac["drds"]),
-                                                  _ptr(jac["drda"]), _ptr(c), _ptr(da), _ptr(ds0), self._stream()))
+            off, tot = shard if shard is not None else (0, B)
+            lib.check(self.L.mbrl_vjp_scan_sharded(self.h, B, H, gw, lib.TIME_MAJOR if time_major else lib.EPISODE_MAJOR,
+                                                   int(off), int(tot), _ptr(jac["dsds"]), _ptr(jac["dsda"]),
+                                                   _ptr(jac["drds"]), _ptr(jac["drda"]), _ptr(c), _ptr(da), _ptr(ds0),
+                                                   self._stream()))
         return da, ds0

@@ -4,27 +4,77 @@ freeze; output/<ENV>/<timestamp|NAME>/{weights,results[,recordings]} and logs.tx
 Modes other than "train" (the learned-dynamics trainer, main.py:47-72) are outside the FD path."""
 import argparse
 import os
+import socket
+import subprocess
+import sys
 from datetime import datetime
 
 from . import config, trainer
 
 
-def train(cfg, iter, device=None):
+def train(cfg, iter, device=None, engine=None):
+    """main.py:12-44.  Under torch.distributed (one process per GPU) rank 0 creates the output directories and
+    broadcasts their name (the default name is a timestamp); the other ranks log to stdout only."""
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank = dist.get_rank() if multi else 0
     env_output_dir = os.path.join(cfg.OUTPUT.DIR, cfg.MUJOCO.ENV)
     name = "{0:%Y-%m-%d %H:%M:%S}".format(datetime.now()) if cfg.OUTPUT.NAME == "timestamp" else cfg.OUTPUT.NAME
+    if multi:
+        box = [name]
+        dist.broadcast_object_list(box, src=0)
+        name = box[0]
     output_dir = os.path.join(env_output_dir, name)
     output_rec_dir = os.path.join(output_dir, "recordings")
     output_weights_dir = os.path.join(output_dir, "weights")
     output_results_dir = os.path.join(output_dir, "results")
-    os.makedirs(output_dir)
-    os.mkdir(output_weights_dir)
-    os.mkdir(output_results_dir)
-    logger = trainer.setup_logger("model.engine.trainer", output_dir, "logs")
-    logger.info("Running with config:\n{}".format(cfg))
+    if rank == 0:
+        os.makedirs(output_dir)
+        os.mkdir(output_weights_dir)
+        os.mkdir(output_results_dir)
+    if multi:
+        dist.barrier()
+    logger = trainer.setup_logger("model.engine.trainer", output_dir if rank == 0 else None, "logs")
+    if rank == 0:
+        logger.info("Running with config:\n{}".format(cfg))
     agent = None
     for i in range(iter):
-        agent = trainer.do_training(cfg, logger, output_results_dir, output_rec_dir, output_weights_dir, i, device=device)
+        agent = trainer.do_training(cfg, logger, output_results_dir, output_rec_dir, output_weights_dir, i, device=device,
+                                    engine=engine)
     return agent, output_dir
+
+
+def launch_ranks(n, argv):
+    """`--gpus n`: start n ranks of this command line as fresh child processes, one per GPU.  The parent has not touched
+    the GPU and never does (nothing is exec'ed after HIP initialisation); returns the worst exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, "-m", "mbrl_amd.main"] + list(argv), env=env))
+    return max(p.wait() for p in procs)
+
+
+def init_distributed(backend=None):
+    """One process per GPU, started by `--gpus n` or by torch.distributed.run: join the process group named by RANK /
+    WORLD_SIZE / MASTER_* and bind this rank to GPU LOCAL_RANK.  Returns the device string (None: single process)."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return None
+    local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        return "cuda:%d" % local
+    dist.init_process_group(backend)
+    return None
 
 
 def main(argv=None):
@@ -32,8 +82,13 @@ def main(argv=None):
     parser.add_argument("--config-file", default="", metavar="file", help="path to config file", type=str)
     parser.add_argument("--mode", default="train", metavar="mode", help="'train'", type=str)
     parser.add_argument("--iter", default=1, help="Number of iterations", type=int)
+    parser.add_argument("--gpus", default=1, type=int,
+                        help="GPUs of this node to shard the episodes over (one process each, RCCL all-reduce)")
     parser.add_argument("--opts", help="Modify config options using the command-line", default=[], nargs=argparse.REMAINDER)
     args = parser.parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else argv))
+    device = init_distributed()
     cfg = config.get_cfg_defaults()
     if args.config_file:
         cfg.merge_from_file(args.config_file)
@@ -41,7 +96,11 @@ def main(argv=None):
     cfg.freeze()
     if args.mode != "train":
         raise SystemExit("mode %r is outside the FD path; only 'train' is built" % args.mode)
-    train(cfg, args.iter)
+    train(cfg, args.iter, device=device)
+    if device is not None:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

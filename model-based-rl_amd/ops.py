@@ -49,12 +49,15 @@ def mj_torch_block_factory(agent, mode):
             # 'prioritise': the reference visits episodes one after the other (last to first) and lets
             # agent.running_sum carry over between them (mujoco.py:65); when B episodes advance together the sum
             # episode b has seen is the scalar accumulated over its own steps plus what the later episodes added
+            # -- of the WHOLE batch: under sharding (agent.episode_offset, agent.total_batch) the later episodes of the
+            # other ranks count too, so that a sharded run weights exactly like a single-process run
             def running_sum():
                 B, H = agent.batch, P.MAX_HORIZON_STEPS
-                if B == 1:
+                first, total = getattr(agent, "episode_offset", 0), getattr(agent, "total_batch", None) or B
+                if total == 1:
                     return agent.running_sum
-                off = torch.arange(B - 1, -1, -1, dtype=torch.float64, device=grad_output.device) * (0.5 * H * (H + 1))
-                return (agent.running_sum + off).reshape(B, 1, 1)
+                later = total - 1 - first - torch.arange(B, dtype=torch.float64, device=grad_output.device)
+                return (agent.running_sum + later * (0.5 * H * (H + 1))).reshape(B, 1, 1)
 
             if mode == "dynamics":
                 state_jacobian = agent.dynamics_gradients["state"]

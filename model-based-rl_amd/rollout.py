@@ -65,9 +65,18 @@ class Linearisation:
         self.jac = engine.new_outputs(B * H)
         self.stream = engine.side_stream()
         self.next_t = 0
+        self._recorded = False
+        # the Jacobian buffers were allocated on the caller's stream and are written on the side stream: tell the
+        # caching allocator, so that their blocks are not handed out again while a side-stream launch may still run
+        for t in self.jac.values():
+            t.record_stream(self.stream)
 
     def submit(self, Q, V, A, t_done):
         """Called on the rollout's stream after step t_done - 1 was enqueued: linearise the finished chunks."""
+        if not self._recorded:      # the rollout's state / action buffers are read on the side stream
+            for t in (Q, V, A):
+                t.record_stream(self.stream)
+            self._recorded = True
         while self.next_t < self.H and (self.next_t + self.chunk <= t_done or t_done >= self.H):
             t0, t1 = self.next_t, min(self.H, self.next_t + self.chunk)
             self.next_t = t1
@@ -78,8 +87,20 @@ class Linearisation:
                 sl = slice(t0 * self.B, t1 * self.B)
                 out = {k: v[sl] for k, v in self.jac.items()}
                 e = self.eng
+                # schedule: the remembered choice for this size class (single launch until tune() has measured it) --
+                # the measurement blocks the host and must not run here, beside the rollout.  The plan, if any, is the
+                # side stream's own (FdEngine keeps one per stream).
                 e.fd_jacobians(Q[t0:t1].reshape(-1, e.nq), V[t0:t1].reshape(-1, e.nv), A[t0:t1].reshape(-1, e.nu),
-                               eps=self.eps, fd_mode=self.fd_mode, out=out, policy=self.policy)
+                               eps=self.eps, fd_mode=self.fd_mode, out=out, policy=self.policy, planned="cached")
+
+    def tune(self, Q, V, A):
+        """Once per size class, on the caller's stream with the side stream drained (RolloutRewards.backward calls it
+        after wait()): measure which schedule is faster for a chunk of this rollout, for the following epochs."""
+        e, n = self.eng, min(self.chunk, self.H) * self.B
+        if n >= 1024 and e.known_schedule(n, self.fd_mode, 1, self.policy is not None) is None:
+            k = min(self.chunk, self.H)
+            e.tune_schedule(Q[:k].reshape(-1, e.nq), V[:k].reshape(-1, e.nv), A[:k].reshape(-1, e.nu), eps=self.eps,
+                            fd_mode=self.fd_mode, policy=self.policy)
 
     def __del__(self):
         # the side stream reads buffers this object keeps alive (lin.keep): never let them return to the allocator
@@ -105,8 +126,10 @@ class RolloutRewards(torch.autograd.Function):
     backward.py:418-419,460-461).  `grad_weights` is cfg.MODEL.POLICY.GRAD_WEIGHTS."""
 
     @staticmethod
-    def forward(ctx, actions, s0, engine, states, rewards, grad_weights, eps, fd_mode, policy, raise_on_status, lin=None):
+    def forward(ctx, actions, s0, engine, states, rewards, grad_weights, eps, fd_mode, policy, raise_on_status, lin=None,
+                shard=None):
         ctx.engine, ctx.gw, ctx.eps, ctx.fd_mode, ctx.policy, ctx.chk = engine, grad_weights, eps, fd_mode, policy, raise_on_status
+        ctx.shard = shard        # (first episode, episodes of the whole batch) of a sharded run, or None
         ctx.lin = lin            # Linearisation already under way on the side stream (rollout_with_policy), or None
         ctx.save_for_backward(actions.detach(), states)
         # the reference's reward op rounds through fp32 (torch.Tensor([r]).double(), mujoco.py:38); kept
@@ -120,6 +143,9 @@ class RolloutRewards(torch.autograd.Function):
         if ctx.lin is not None:
             ctx.lin.wait()
             jac = ctx.lin.jac
+            keep = getattr(ctx.lin, "keep", None)
+            if keep is not None:
+                ctx.lin.tune(*keep)
         else:
             s = states[:, :H].reshape(B * H, eng.n)
             jac = eng.fd_jacobians(s[:, :eng.nq], s[:, eng.nq:], actions.reshape(B * H, nu), eps=ctx.eps,
@@ -128,12 +154,21 @@ class RolloutRewards(torch.autograd.Function):
             bad = int((jac["status"] != 0).sum())
             if bad:
                 raise lib.MbrlError("FD linearisation flagged %d of %d units (status bits, include/mbrl.h)" % (bad, B * H))
+        else:
+            # Flagged units (MBRL_ST_*): their Jacobians are not to be trusted.  Cut the episode's gradient chain there:
+            # zero Jacobians and zero loss weight for the flagged unit, so nothing flows through or out of it (the
+            # trainer masks the same episodes' losses, as the reference's NaN-loss rule does, strategies.py:191-192).
+            flagged = jac["status"] != 0
+            if bool(flagged.any()):
+                jac = dict(jac)
+                for k in ("dsds", "dsda", "drds", "drda"):
+                    jac[k] = jac[k].masked_fill(flagged.reshape((-1,) + (1,) * (jac[k].dim() - 1)), 0.0)
         if ctx.lin is not None:
-            da, ds0 = eng.vjp_scan(jac, c.t().contiguous(), ctx.gw, time_major=True)
+            da, ds0 = eng.vjp_scan(jac, c.t().contiguous(), ctx.gw, time_major=True, shard=ctx.shard)
             da = da.permute(1, 0, 2)
         else:
-            da, ds0 = eng.vjp_scan(jac, c.contiguous(), ctx.gw)
-        return da, ds0, None, None, None, None, None, None, None, None, None
+            da, ds0 = eng.vjp_scan(jac, c.contiguous(), ctx.gw, shard=ctx.shard)
+        return da, ds0, None, None, None, None, None, None, None, None, None, None
 
 
 def rollout_with_policy(engine, agent, model_policy, s0, horizon, linearise=None):

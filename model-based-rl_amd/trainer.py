@@ -60,7 +60,9 @@ def build_model(cfg, agent, shard=None):
     return model
 
 
-def do_training(cfg, logger, output_results_dir, output_rec_dir, output_weights_dir, iter, device=None):
+def do_training(cfg, logger, output_results_dir, output_rec_dir, output_weights_dir, iter, device=None, engine=None):
+    """`engine`: an object with FdEngine's interface to use instead of creating one on `device` (the world-size-2 CPU
+    test passes a stand-in; the product path always creates the HIP engine)."""
     rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     if cfg.MODEL.RANDOM_SEED > 0:                                   # trainer.py:21-23
@@ -71,7 +73,7 @@ def do_training(cfg, logger, output_results_dir, output_rec_dir, output_weights_
     lo, hi = parallel.shard_range(B, rank, world)                   # this rank's episodes
     if hi - lo < 1:
         raise ValueError("MODEL.BATCH_SIZE %d is smaller than the number of ranks %d" % (B, world))
-    agent = build_agent(cfg, batch=hi - lo, device=device)
+    agent = build_agent(cfg, batch=hi - lo, device=device, engine=engine, shard=(lo, B))
     model = build_model(cfg, agent, shard=(lo, hi))                 # same seed on every rank: identical parameters
     model.train()
     policy, eng = model.policy_net, agent.engine
@@ -98,12 +100,18 @@ def do_training(cfg, logger, output_results_dir, output_rec_dir, output_weights_
             states, actions, rewards, status, lin = rollout.rollout_with_policy(
                 eng, agent, policy, s0, H,
                 linearise=dict(eps=eps, fd_mode=fd_mode, policy=fd_policy, chunk=overlap) if overlap > 0 else None)
-            bad = int((status != 0).sum())
-            if bad:
-                raise lib.MbrlError("rollout flagged %d steps (status bits, include/mbrl.h)" % bad)
             r = rollout.RolloutRewards.apply(actions, s0, eng, states, rewards, cfg.MODEL.POLICY.GRAD_WEIGHTS,
-                                             eps, fd_mode, fd_policy, True, lin)
+                                             eps, fd_mode, fd_policy, False, lin, (lo, B))
             batch_loss[:] = -r
+            # A step the simulator flagged (MBRL_ST_*: non-finite state, solver at its iteration cap, ...) ends that
+            # episode's contribution: its loss from there on is NaN, which `optimize` turns into zero loss and zero
+            # gradient (the reference's own rule, strategies.py:191-192); mujoco-py would have raised instead.
+            dead = (status != 0).cumsum(dim=1) > 0
+            if bool(dead.any()):
+                batch_loss = batch_loss.masked_fill(dead, float("nan"))
+                if rank == 0:
+                    logger.warning("epoch %d: %d of %d episodes masked from their first flagged step (status bits, "
+                                   "include/mbrl.h)" % (epoch_idx, int(dead.any(dim=1).sum()), hi - lo))
         agent.running_sum = 0                                       # trainer.py:76
         loss = policy.optimize(batch_loss, grad_sync=grad_sync if world > 1 else None)   # trainer.py:77
         if world > 1:   # logged objective = batch mean of episode losses over ALL ranks' episodes

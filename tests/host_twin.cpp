@@ -3,21 +3,55 @@
 // counts its floating-point operations (FMA = 2, add/mul = 1, div/sqrt/transcendental = 1).
 #include <cstdint>
 #include <cstring>
+#include <thread>
+#include <vector>
 #include "../model-based-rl_amd/csrc/planar_lean.hpp"
 
 namespace mbrl {
+// Counting scalar.  What is charged is what the device compiler has to execute, not what the source spells out: the
+// kernel is compiled with no-NaN / no-infinity / no-signed-zero arithmetic (build.py), under which a product with a
+// COMPILE-TIME 0 or +-1 and a sum with a compile-time 0 fold away (model tables are full of such entries: slide-joint
+// motion subspaces, zero offsets, dof signs).  A Cnt built from a plain double is such a compile-time constant (`k`);
+// run-time data enters through Cnt::var() (Host::load) and every charged operation yields a run-time value.  An
+// operation on two constants is folded by the compiler and costs nothing.
 struct Cnt {
     double x;
-    static long long n;
-    Cnt() : x(0) {}
-    Cnt(double v) : x(v) {}
+    bool k;                       // compile-time constant
+    static thread_local long long n;
+    Cnt() : x(0), k(true) {}
+    Cnt(double v) : x(v), k(true) {}
+    static Cnt var(double v) { Cnt r; r.x = v; r.k = false; return r; }
+    static Cnt konst(double v, bool kk) { Cnt r; r.x = v; r.k = kk; return r; }
+    bool is0() const { return k && x == 0.0; }
+    bool is1() const { return k && (x == 1.0 || x == -1.0); }
 };
-long long Cnt::n = 0;
-inline Cnt operator+(Cnt a, Cnt b) { Cnt::n++; return Cnt(a.x + b.x); }
-inline Cnt operator-(Cnt a, Cnt b) { Cnt::n++; return Cnt(a.x - b.x); }
-inline Cnt operator*(Cnt a, Cnt b) { Cnt::n++; return Cnt(a.x * b.x); }
-inline Cnt operator/(Cnt a, Cnt b) { Cnt::n++; return Cnt(a.x / b.x); }
-inline Cnt operator-(Cnt a) { return Cnt(-a.x); }
+thread_local long long Cnt::n = 0;
+inline Cnt operator+(Cnt a, Cnt b) {
+    if (a.k && b.k) return Cnt(a.x + b.x);
+    if (a.is0()) return Cnt::var(b.x);
+    if (b.is0()) return Cnt::var(a.x);
+    Cnt::n++; return Cnt::var(a.x + b.x);
+}
+inline Cnt operator-(Cnt a, Cnt b) {
+    if (a.k && b.k) return Cnt(a.x - b.x);
+    if (a.is0()) return Cnt::var(-b.x);      // negation is an operand modifier
+    if (b.is0()) return Cnt::var(a.x);
+    Cnt::n++; return Cnt::var(a.x - b.x);
+}
+inline Cnt operator*(Cnt a, Cnt b) {
+    if (a.k && b.k) return Cnt(a.x * b.x);
+    if (a.is0() || b.is0()) return Cnt(0.0);                     // x * 0 = 0 under no-NaN / no-signed-zero
+    if (a.is1()) return Cnt::var(a.x * b.x);
+    if (b.is1()) return Cnt::var(a.x * b.x);
+    Cnt::n++; return Cnt::var(a.x * b.x);
+}
+inline Cnt operator/(Cnt a, Cnt b) {
+    if (a.k && b.k) return Cnt(a.x / b.x);
+    if (a.is0()) return Cnt(0.0);
+    if (b.is1()) return Cnt::var(a.x / b.x);
+    Cnt::n++; return Cnt::var(a.x / b.x);     // (division by another constant is a multiplication: 1 either way)
+}
+inline Cnt operator-(Cnt a) { return Cnt::konst(-a.x, a.k); }
 inline Cnt operator+(double a, Cnt b) { return Cnt(a) + b; }
 inline Cnt operator-(double a, Cnt b) { return Cnt(a) - b; }
 inline Cnt operator*(double a, Cnt b) { return Cnt(a) * b; }
@@ -26,18 +60,29 @@ inline Cnt operator+(Cnt a, double b) { return a + Cnt(b); }
 inline Cnt operator-(Cnt a, double b) { return a - Cnt(b); }
 inline Cnt operator*(Cnt a, double b) { return a * Cnt(b); }
 inline Cnt operator/(Cnt a, double b) { return a / Cnt(b); }
-inline Cnt t_abs(Cnt a) { return Cnt(fabs(a.x)); }
-inline Cnt t_max(Cnt a, Cnt b) { return Cnt(fmax(a.x, b.x)); }
-inline Cnt t_min(Cnt a, Cnt b) { return Cnt(fmin(a.x, b.x)); }
-inline Cnt t_sqrt(Cnt a) { Cnt::n++; return Cnt(sqrt(a.x)); }
-inline Cnt t_pow(Cnt a, Cnt b) { Cnt::n++; return Cnt(pow(a.x, b.x)); }
-inline Cnt t_fmod(Cnt a, Cnt b) { Cnt::n++; return Cnt(fmod(a.x, b.x)); }
-inline Cnt t_cos(Cnt a) { Cnt::n++; return Cnt(cos(a.x)); }
-inline Cnt t_fma(Cnt a, Cnt b, Cnt c) { Cnt::n += 2; return Cnt(__builtin_fma(a.x, b.x, c.x)); }
-inline Cnt t_rint(Cnt a) { return Cnt(__builtin_rint(a.x)); }
-inline Cnt t_rcp(Cnt a) { Cnt::n++; return Cnt(1.0 / a.x); }
+inline Cnt t_abs(Cnt a) { return Cnt::konst(fabs(a.x), a.k); }
+inline Cnt t_max(Cnt a, Cnt b) { return Cnt::konst(fmax(a.x, b.x), a.k && b.k); }
+inline Cnt t_min(Cnt a, Cnt b) { return Cnt::konst(fmin(a.x, b.x), a.k && b.k); }
+inline Cnt t_sqrt(Cnt a) { if (a.k) return Cnt(sqrt(a.x)); Cnt::n++; return Cnt::var(sqrt(a.x)); }
+inline Cnt t_pow(Cnt a, Cnt b) { if (a.k && b.k) return Cnt(pow(a.x, b.x)); Cnt::n++; return Cnt::var(pow(a.x, b.x)); }
+inline Cnt t_fmod(Cnt a, Cnt b) { if (a.k && b.k) return Cnt(fmod(a.x, b.x)); Cnt::n++; return Cnt::var(fmod(a.x, b.x)); }
+inline Cnt t_cos(Cnt a) { if (a.k) return Cnt(cos(a.x)); Cnt::n++; return Cnt::var(cos(a.x)); }
+inline Cnt t_fma(Cnt a, Cnt b, Cnt c) {          // a * b + c with the same folding rules
+    if (a.k && b.k && c.k) return Cnt(__builtin_fma(a.x, b.x, c.x));
+    const double r = __builtin_fma(a.x, b.x, c.x);
+    const bool prod_free = (a.k && b.k) || a.is0() || b.is0() || a.is1() || b.is1();
+    const bool prod_zero = a.is0() || b.is0();
+    const bool add_free = prod_zero || c.is0();
+    Cnt::n += (prod_free ? 0 : 1) + (add_free ? 0 : 1);
+    return Cnt::var(r);
+}
+inline Cnt t_rint(Cnt a) { return Cnt::konst(__builtin_rint(a.x), a.k); }
+inline Cnt t_rcp(Cnt a) { if (a.k) return Cnt(1.0 / a.x); Cnt::n++; return Cnt::var(1.0 / a.x); }
 inline bool t_finite(Cnt a) { return a.x - a.x == 0.0; }
 inline double t_val(Cnt a) { return a.x; }
+template <class T> inline T t_var(double v);          // run-time input value
+template <> inline double t_var<double>(double v) { return v; }
+template <> inline Cnt t_var<Cnt>(double v) { return Cnt::var(v); }
 }  // namespace mbrl
 
 using namespace mbrl;
@@ -49,8 +94,8 @@ struct Host {
     void load(const double *q, const double *v, const double *c) {
         using LY = Layout<M>;
         S.mem.p = col;
-        for (int j = 0; j < M::NV; j++) { col[LY::OQ + j] = T(q[j]); col[LY::OV + j] = T(v[j]); }
-        for (int u = 0; u < M::NU; u++) col[LY::OC + u] = T(c[u]);
+        for (int j = 0; j < M::NV; j++) { col[LY::OQ + j] = t_var<T>(q[j]); col[LY::OV + j] = t_var<T>(v[j]); }
+        for (int u = 0; u < M::NU; u++) col[LY::OC + u] = t_var<T>(c[u]);
         S.status = 0;
     }
 };
@@ -114,5 +159,38 @@ long long twin_count_flops(int id, int frame_skip, int64_t N, const double *q, c
     Cnt::n = 0;
     DISPATCH(id, (stepN<M, Cnt>(frame_skip, N, q, v, c, qn, vn, r, st)));
     return Cnt::n;
+}
+// the same over `nthreads` host threads (contiguous slices of the N rollouts; the counter is per thread)
+long long twin_count_flops_mt(int id, int frame_skip, int64_t N, const double *q, const double *v, const double *c,
+                              double *qn, double *vn, double *r, uint32_t *st, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    std::vector<long long> part(nthreads, 0);
+    std::vector<std::thread> th;
+    int nv = 0, nu = 0;
+    DISPATCH(id, (nv = M::NV, nu = M::NU));
+    for (int t = 0; t < nthreads; t++)
+        th.emplace_back([&, t]() {
+            const int64_t lo = N * t / nthreads, hi = N * (t + 1) / nthreads;
+            part[t] = twin_count_flops(id, frame_skip, hi - lo, q + lo * nv, v + lo * nv, c + lo * nu, qn + lo * nv,
+                                       vn + lo * nv, r + lo, st + lo);
+        });
+    long long tot = 0;
+    for (int t = 0; t < nthreads; t++) { th[t].join(); tot += part[t]; }
+    return tot;
+}
+// Newton passes (Hessian builds) and line-search evaluations summed over N single mj_forward calls at the given states,
+// and the number of those that were constrained -- BASELINE.md's "mean Newton passes" figure
+int twin_solver_stats(int id, int64_t N, const double *q, const double *v, const double *c, long long *passes,
+                      long long *line_evals, long long *constrained) {
+    *passes = 0; *line_evals = 0; *constrained = 0;
+    int nv = 0, nu = 0;
+    DISPATCH(id, (nv = M::NV, nu = M::NU));
+    for (int64_t i = 0; i < N; i++) {
+        double qa[32], fs[32], fc[32];
+        int it = 0, na = 0;
+        (void)twin_forward(id, q + i * nv, v + i * nv, c + i * nu, qa, fs, fc, &it, &na);
+        *passes += it; *constrained += it > 0 ? 1 : 0;
+    }
+    return 0;
 }
 }

@@ -186,3 +186,38 @@ def test_planned_launch_needs_a_plan_for_the_same_batch():
     torch.cuda.synchronize()
     assert bool((o["status"] == 0).all())
     assert torch.equal(o["dsds"], e.fd_jacobians(q, v, c, planned=False)["dsds"])
+
+
+def test_two_streams_linearise_side_by_side_with_their_own_plans():
+    """FdEngine keeps one launch plan per stream: two linearisations interleaved on two streams (plan A, plan B,
+    planned A, planned B -- the order that would trample a shared plan) give the single-stream bits."""
+    import torch
+    e = _eng("HalfCheetahEnv")
+    qa, va, ca = _states(e, 2500, seed=21)
+    qb, vb, cb = _states(e, 1700, seed=22)
+    ref_a = e.fd_jacobians(qa, va, ca, planned=True)
+    ref_b = e.fd_jacobians(qb, vb, cb, planned=True)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    oa, ob = e.new_outputs(2500), e.new_outputs(1700)
+    with torch.cuda.stream(s1):
+        e.fd_plan(qa, va, ca, out=oa)
+    with torch.cuda.stream(s2):
+        e.fd_plan(qb, vb, cb, out=ob)
+    with torch.cuda.stream(s1):
+        e.fd_planned(qa, va, ca, oa)
+    with torch.cuda.stream(s2):
+        e.fd_planned(qb, vb, cb, ob)
+    torch.cuda.synchronize()
+    for k in ref_a:
+        assert torch.equal(ref_a[k], oa[k]) and torch.equal(ref_b[k], ob[k]), k
+    # an explicit, caller-owned plan works the same way
+    p = e.new_plan(2500)
+    oc = e.fd_jacobians(qa, va, ca, planned=True, plan=p)
+    torch.cuda.synchronize()
+    assert p.units == 2500 and all(torch.equal(ref_a[k], oc[k]) for k in ref_a)
+    # "cached" never measures: single launch until tune_schedule has run for the size class
+    assert e.known_schedule(2500) is None
+    od = e.fd_jacobians(qa, va, ca, planned="cached")
+    assert e.known_schedule(2500) is None and all(torch.equal(ref_a[k], od[k]) for k in ref_a)
+    assert e.tune_schedule(qa, va, ca) in (True, False) and e.known_schedule(2500) is not None

@@ -135,3 +135,38 @@ def test_scan_layouts_agree():
         da2, ds02 = e.vjp_scan({k: v.reshape((B * H,) + v.shape[2:]) for k, v in tm.items()}, c.t().contiguous(), gw,
                                time_major=True)
         assert torch.equal(da, da2.transpose(0, 1)) and torch.equal(ds0, ds02)
+
+
+@pytest.mark.parametrize("time_major", [False, True])
+def test_sharded_scan_concatenates_to_the_whole_batch(time_major):
+    """mbrl_vjp_scan_sharded: the scans of two shards, each told its global episode offset, concatenate to the scan of
+    the whole batch bit for bit -- for 'prioritise' too, whose running sum carries over between episodes."""
+    import torch
+    import mbrl_amd  # noqa: F401
+    from mbrl_amd.engine import FdEngine
+    e = FdEngine("HopperEnv")
+    B, H, n, nu = 7, 5, e.n, e.nu
+    g = torch.Generator(device="cpu").manual_seed(5)
+    rnd = lambda *s: torch.randn(s, generator=g, dtype=torch.float64).cuda()
+    jac = dict(dsds=rnd(B, H, n, n), dsda=rnd(B, H, n, nu), drds=rnd(B, H, n), drda=rnd(B, H, nu))
+    c = rnd(B, H)
+
+    def scan(lo, hi, gw, shard):
+        sub = {k: v[lo:hi] for k, v in jac.items()}
+        cc = c[lo:hi]
+        if time_major:
+            sub = {k: v.transpose(0, 1).contiguous() for k, v in sub.items()}
+            cc = cc.t().contiguous()
+        flat = {k: v.reshape((-1,) + v.shape[2:]).contiguous() for k, v in sub.items()}
+        da, ds0 = e.vjp_scan(flat, cc, gw, time_major=time_major, shard=shard)
+        return (da.transpose(0, 1) if time_major else da), ds0
+
+    for gw in ("none", "average", "prioritise"):
+        da, ds0 = scan(0, B, gw, None)
+        parts = [scan(lo, hi, gw, (lo, B)) for lo, hi in ((0, 4), (4, 7))]
+        assert torch.equal(da, torch.cat([p[0] for p in parts])) and torch.equal(ds0, torch.cat([p[1] for p in parts])), gw
+    lone, _ = scan(4, 7, "prioritise", None)                    # without the offset the later shard weights differently
+    assert not torch.equal(lone, da[4:7])
+    from mbrl_amd import lib
+    with pytest.raises(lib.MbrlError):
+        scan(4, 7, "average", (5, B))                            # shard sticks out of the batch

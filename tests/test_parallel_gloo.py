@@ -114,3 +114,65 @@ def test_two_rank_strategy_step_matches_single_process(tmp_path):
     ref = strategy_step((0, 6), grad_sync=None)
     for k, v in ref.items():
         np.testing.assert_allclose(got[k], v.numpy(), rtol=1e-12, atol=1e-14)
+
+
+# ---- trainer.do_training under torch.distributed, end to end (world size 2, gloo) ----
+def _train_cfg(weights):
+    import mbrl_amd  # noqa: F401
+    from mbrl_amd import config
+    cfg = config.cfg_for_env("InvertedDoublePendulumEnv")
+    cfg.MODEL.BATCH_SIZE, cfg.MODEL.POLICY.MAX_HORIZON_STEPS, cfg.MODEL.EPOCHS = 5, 4, 3     # 5 episodes: shards of 3 + 2
+    cfg.MODEL.POLICY.ARCH, cfg.MODEL.POLICY.METHOD = "VariationalOptimization", "R"
+    cfg.MODEL.POLICY.INITIAL_SD, cfg.MODEL.RANDOM_SEED = 0.2, 11
+    cfg.MODEL.POLICY.GRAD_WEIGHTS = weights
+    cfg.MODEL.FD_OVERLAP_STEPS = 0            # the stand-in engine has no streams
+    cfg.SOLVER.BASE_LR, cfg.SOLVER.STD_LR_FACTOR, cfg.SOLVER.BIAS_LR_FACTOR = 0.01, 1.0, 1
+    cfg.LOG.CHECKPOINT_PERIOD = 2
+    return cfg
+
+
+def _do_training(weights, out_dir):
+    """main.train (rank-0 directories, broadcast run name) -> trainer.do_training over the CPU stand-in engine."""
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import mbrl_amd  # noqa: F401
+    from mbrl_amd import main as cli
+    from cpu_engine import CpuEngine
+    cfg = _train_cfg(weights)
+    cfg.OUTPUT.DIR, cfg.OUTPUT.NAME = out_dir, "timestamp"
+    agent, run_dir = cli.train(cfg, 1, engine=CpuEngine(cfg.MUJOCO.ENV, cfg.MODEL.FRAME_SKIP))
+    return {k: v.detach().clone() for k, v in agent.policy_net.state_dict().items()}, run_dir
+
+
+def _train_worker(rank, world, port, weights, out_dir, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    params, run_dir = _do_training(weights, out_dir)
+    if rank == 0:
+        np.savez(out, run_dir=run_dir, **{k: v.numpy() for k, v in params.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("weights", ["average", "prioritise"])
+def test_two_rank_do_training_matches_single_process(weights, tmp_path):
+    """The distributed branch of do_training (shard_range, per-shard loss weight, sliced exploration noise, flattened
+    gradient all-reduce, logged objective over all ranks, 'prioritise' seeded with the shard's global episode offset)
+    trains the parameters a single process trains; only rank 0 writes, and every rank agrees on the run directory."""
+    import csv
+    out = str(tmp_path / "p.npz")
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_train_worker, args=(2, port, weights, str(tmp_path / "two"), out), nprocs=2, join=True)
+    got = np.load(out)
+    ref, ref_dir = _do_training(weights, str(tmp_path / "one"))
+    for k, v in ref.items():
+        np.testing.assert_allclose(got[k], v.numpy(), rtol=1e-9, atol=1e-12, err_msg=k)
+    run = str(got["run_dir"])
+    assert sorted(os.listdir(os.path.join(run, "weights"))) == ["iter_0.pth", "iter_2.pth"]
+    rows2 = list(csv.reader(open(os.path.join(run, "results", "output_0"))))
+    rows1 = list(csv.reader(open(os.path.join(ref_dir, "results", "output_0"))))
+    assert rows2[0] == rows1[0] == ["epoch", "objective_loss", "average_sd"]
+    np.testing.assert_allclose([[float(x) for x in r] for r in rows2[1:]], [[float(x) for x in r] for r in rows1[1:]],
+                               rtol=1e-9)
