@@ -29,7 +29,7 @@ extern "C" {
 #define MBRL_ST_NONFINITE  1u  /* NaN/Inf state or non-positive pivot */
 #define MBRL_ST_NOCONVERGE 2u  /* constraint solver hit its iteration cap */
 #define MBRL_ST_OVERFLOW   4u  /* reserved (contact capacity) */
-#define MBRL_ST_DEGENERATE 8u  /* two capsule axes cross (distance 0): that contact's normal is undefined */
+#define MBRL_ST_DEGENERATE 8u  /* reserved; not raised since ABI 6: crossing capsule axes have a defined normal */
 #define MBRL_ST_BADPLAN    16u /* mbrl_fd_jacobians_planned: the plan was made for another batch (N, nsteps, model) */
 
 #define MBRL_FD_FORWARD 0      /* reference parity: one-sided, (f(x+eps)-f(x))/eps, backward.py:402-406 */

@@ -631,10 +631,21 @@ struct Lean {
             const T dfa = c2a - c1a, dfb = c2b - c1b;
             const T len = t_sqrt(dfa * dfa + dfb * dfb);
             const T dist = len - M::g_rad[g1] - M::g_rad[g2];
-            if (t_val(dist) < M::pair_margin[k]) {
-                if (t_val(len) < 1e-10) status |= ST_DEGENERATE;  // crossing axes: normal is round-off noise
+            // Crossing axes: the closest points coincide and their difference is round-off noise.  (In a plane this is
+            // no rare event: two segments cross over a whole range of poses, e.g. a Hopper that has folded through
+            // itself.)  Rule, MuJoCo's sphere-sphere one [from knowledge, mjraw_SphereSphere]: the normal is the cross
+            // product of the two capsule axes, or (1,0,0) when those are parallel.  For a planar model that cross product
+            // points OUT of the plane, so the row acts on no dof and exerts no force: the pair gets no row at all.
+            // The rule applies below 1e-10 (MuJoCo: 1e-15, and a normalised noise vector in between -- not reproducible
+            // by any second implementation), identically in the oracle (sphereSphere in oracle/mjc_oracle.c).
+            bool inert = false;
+            if (t_val(len) < 1e-10) {
+                const T cr = d1a * d2b - d1b * d2a;
+                inert = t_val(cr) * t_val(cr) >= (kMinVal * kMinVal) * (t_val(aa) * t_val(ee));
+            }
+            if (t_val(dist) < M::pair_margin[k] && !inert) {
                 T na = T(1.0), nb = T(0.0);
-                if (!(t_val(len) < kMinVal)) { na = dfa / len; nb = dfb / len; }
+                if (!(t_val(len) < 1e-10)) { na = dfa / len; nb = dfb / len; }
                 const T Pa = c1a + na * (M::g_rad[g1] + T(0.5) * dist);
                 const T Pb = c1b + nb * (M::g_rad[g1] + T(0.5) * dist);
                 const T pm = dist - M::pair_margin[k];

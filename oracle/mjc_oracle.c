@@ -379,15 +379,24 @@ static void segseg(const double *p1, const double *d1, const double *p2, const d
     *s_out = s; *t_out = t;
 }
 
+/* ax1, ax2: the two capsule axes (any length).  Coinciding centres (crossing axes): normal = cross product of the axes,
+ * or (1,0,0) when they are parallel [MJ mjraw_SphereSphere, from knowledge].  The rule applies below 1e-10 (MuJoCo: 1e-15
+ * and a normalised round-off vector in between, which no second implementation can reproduce); the kernel does the same
+ * (planar_lean.hpp: for a planar model the cross product points out of the plane, so the row acts on no dof). */
 static void sphereSphere(Data *d, const Contact *proto, const double *c1, double r1, const double *c2, double r2,
-                         int b1, int b2) {
+                         int b1, int b2, const double *ax1, const double *ax2) {
     double dif[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
     double len = sqrt(dot3(dif, dif));
     double dist = len - r1 - r2;
     if (dist >= proto->includemargin) return;
     Contact c = *proto;
-    if (len < 1e-10) d->status |= MJO_ST_DEGENERATE; /* crossing axes: the normal is round-off noise */
-    if (len < MINVAL) { c.frame[0] = 1; c.frame[1] = 0; c.frame[2] = 0; }
+    if (len < 1e-10) {
+        double cr[3];
+        cross3(cr, ax1, ax2);
+        double n2 = dot3(cr, cr), l2 = dot3(ax1, ax1) * dot3(ax2, ax2);
+        if (n2 >= MINVAL * MINVAL * l2) { double n = sqrt(n2); for (int k = 0; k < 3; k++) c.frame[k] = cr[k] / n; }
+        else { c.frame[0] = 1; c.frame[1] = 0; c.frame[2] = 0; }
+    }
     else for (int k = 0; k < 3; k++) c.frame[k] = dif[k] / len;
     for (int k = 0; k < 3; k++) c.pos[k] = c1[k] + c.frame[k] * (r1 + 0.5 * dist);
     makeFrame(c.frame);
@@ -439,7 +448,7 @@ static void collision(const Model *m, Data *d) {
                 segseg(a1, d1, a2, d2, &s, &t, &par);
                 double c1[3], c2[3];
                 for (int k = 0; k < 3; k++) { c1[k] = a1[k] + s * d1[k]; c2[k] = a2[k] + t * d2[k]; }
-                sphereSphere(d, &proto, c1, G1->radius, c2, G2->radius, b1, b2);
+                sphereSphere(d, &proto, c1, G1->radius, c2, G2->radius, b1, b2, d1, d2);
             }
     }
 }

@@ -39,7 +39,7 @@ extern "C" {
 #define MJO_ST_NONFINITE   1u   /* NaN/Inf in state or acceleration */
 #define MJO_ST_NOCONVERGE  2u   /* constraint solver hit its iteration cap */
 #define MJO_ST_OVERFLOW    4u   /* contact capacity exceeded */
-#define MJO_ST_DEGENERATE  8u   /* capsule axes cross (distance 0): contact normal undefined */
+#define MJO_ST_DEGENERATE  8u   /* reserved (crossing capsule axes now have a defined normal, see sphereSphere) */
 
 /* ---- raw transcription (filled by models_raw_gen.h) ---- */
 typedef struct {

@@ -32,12 +32,12 @@ def test_step_matches_oracle(env, torch_cuda):
     from oracle import Oracle
     o = Oracle(env)
     e = _engine(env)
-    q, v, c = util.on_trajectory(o, env, 512, seed=0)
+    q, v, c = util.on_trajectory(o, env, 512, seed=0, max_steps=39)     # whole horizon: Hopper has fallen and folded by then
     qo, vo, ro, so = o.step(q, v, c, nthreads=8)
     qn, vn, r, st = e.step(q, v, c)
     assert (st.cpu().numpy() == so.astype(np.int32)).all()
-    ok = so == 0          # units whose physics is well defined (no crossing capsule axes, solver converged)
-    assert ok.mean() > 0.8
+    ok = so == 0          # units the simulator did not flag (solver converged, finite)
+    assert ok.mean() >= 0.99
     assert util.relerr(qn.cpu().numpy()[ok], qo[ok]) < 1e-11
     assert util.relerr(vn.cpu().numpy()[ok], vo[ok]) < 1e-10
     assert util.relerr(r.cpu().numpy()[ok], ro[ok]) < 1e-10
@@ -49,13 +49,13 @@ def test_fd_jacobians_match_oracle(env, fd_mode, torch_cuda):
     from oracle import Oracle
     o = Oracle(env)
     e = _engine(env)
-    q, v, c = util.on_trajectory(o, env, 300, seed=1)
+    q, v, c = util.on_trajectory(o, env, 300, seed=1, max_steps=39)
     ref = o.fd_jacobians(q, v, c, fd_mode=fd_mode, nthreads=8)
     out = e.fd_jacobians(q, v, c, fd_mode=fd_mode)
     got = {k: t.cpu().numpy() for k, t in out.items()}
     assert (got["status"] == ref["status"].astype(np.int32)).all()
     ok = ref["status"] == 0
-    assert ok.mean() > 0.8
+    assert ok.mean() >= 0.99
     got = {k: a[ok] for k, a in got.items()}
     ref = {k: a[ok] for k, a in ref.items()}
     q = q[ok]

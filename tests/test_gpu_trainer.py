@@ -165,8 +165,49 @@ def test_sharded_scan_concatenates_to_the_whole_batch(time_major):
         da, ds0 = scan(0, B, gw, None)
         parts = [scan(lo, hi, gw, (lo, B)) for lo, hi in ((0, 4), (4, 7))]
         assert torch.equal(da, torch.cat([p[0] for p in parts])) and torch.equal(ds0, torch.cat([p[1] for p in parts])), gw
-    lone, _ = scan(4, 7, "prioritise", None)                    # without the offset the later shard weights differently
-    assert not torch.equal(lone, da[4:7])
+    lone, _ = scan(0, 4, "prioritise", None)                    # without the offset the first shard weights differently
+    assert not torch.equal(lone, da[0:4])
     from mbrl_amd import lib
     with pytest.raises(lib.MbrlError):
         scan(4, 7, "average", (5, B))                            # shard sticks out of the batch
+
+
+def test_hopper_trains_through_a_fall(tmp_path):
+    """Hopper under exploration noise falls and folds through itself within the horizon (capsule axes cross): the
+    simulator keeps returning steps (as MuJoCo does) and the trainer keeps training -- no status flag, finite losses."""
+    cfg = _cfg("HopperEnv", B=16, H=40, epochs=2, MODEL__POLICY__INITIAL_SD=0.5)
+    agent, rows, d = _train(cfg, tmp_path, "hop")
+    assert all(np.isfinite(float(r[1])) for r in rows[1:])
+
+
+def test_flagged_episodes_are_masked_not_fatal():
+    """An episode the simulator flags (here: a NaN initial state -> MBRL_ST_NONFINITE) contributes zero loss and zero
+    gradient from its first flagged step on (the reference's NaN-loss rule, strategies.py:191-192); the other episodes
+    train as if it were not there."""
+    import torch
+    from mbrl_amd import rollout
+    from mbrl_amd.agent import build_agent
+    from mbrl_amd.strategies import build_policy
+    grads = {}
+    for poison in (False, True):
+        cfg = _cfg("HalfCheetahEnv", B=6, H=8, epochs=1)
+        torch.manual_seed(3); np.random.seed(3)
+        agent = build_agent(cfg, batch=6)
+        policy = build_policy(cfg, agent)
+        eng = agent.engine
+        s0 = agent.reset().clone()
+        if poison:
+            s0[2, 1] = float("nan")
+        states, actions, rewards, status, lin = rollout.rollout_with_policy(eng, agent, policy, s0, 8)
+        r = rollout.RolloutRewards.apply(actions, s0, eng, states, rewards, "average", 1e-6, 0, None, False, None, None)
+        dead = (status != 0).cumsum(dim=1) > 0
+        assert bool(dead[2].all()) == poison and not bool(dead[[0, 1, 3, 4, 5]].any())
+        loss = (-r).masked_fill(dead, float("nan"))
+        # sum over the healthy episodes only, so that both runs optimise the same objective
+        keep = torch.tensor([0, 1, 3, 4, 5], device=loss.device)
+        z = torch.where(torch.isnan(loss), torch.zeros_like(loss), loss)
+        policy.optimizer.zero_grad()
+        (z[keep].sum() + z[2].sum() * (1.0 if poison else 0.0)).backward()
+        grads[poison] = [p.grad.clone() for p in policy.parameters() if p.grad is not None]
+    for a, b in zip(grads[False], grads[True]):
+        assert torch.isfinite(b).all() and torch.allclose(a, b, rtol=1e-12, atol=1e-14)
