@@ -154,7 +154,7 @@ def main():
             td.barrier()
         torch.cuda.synchronize()
 
-    def timed(fd_mode, steps, warmup):
+    def timed(fd_mode, steps, warmup, serial=False):
         """K linearisations of the batch.  One step = mbrl_fd_plan (nominal rollouts + unit order) and
         mbrl_fd_jacobians_planned (the perturbed rollouts: the dominant kernel); --single-launch: mbrl_fd_jacobians.
         Default schedule: two plan buffers; the plan of step k+1 is launched on a second stream while the perturbed
@@ -162,7 +162,7 @@ def main():
         inside the timed region.  Returns wall seconds, mean plan ms, mean kernel ms (HIP events on the stream the
         kernel runs on), outputs."""
         out = eng.new_outputs(N)
-        pipelined = not (a.single_launch or a.serial_plan)
+        pipelined = not (a.single_launch or a.serial_plan or serial)
         plans = [eng.new_plan(N) for _ in range(2 if pipelined else 1)]
         side = eng.side_stream() if pipelined else main_stream
         nom = [dict(s_next=out["s_next"], reward=out["reward"], status=eng._new(N, dtype=torch.int32)) for _ in plans]
@@ -224,6 +224,13 @@ def main():
         el2, p2, k2, _, _ = timed(1, ks, 1)
         extra["central"] = {"value": world * N * ks / el2, "unit": "Jacobians/s", "steps": ks, "ms_per_step": el2 / ks * 1e3,
                             "kernel_ms": k2, "plan_ms": p2, "rollouts_per_unit": 2 * (eng.n + eng.nu) + 1}
+    if not a.no_extra and pipelined:
+        # the same step with its two launches strictly one after the other on one stream: the dominant kernel alone
+        # on the chip (its un-overlapped duration) and the plan launch's own cost
+        ks = max(3, min(a.steps, 10))
+        el3, p3, k3, _, _ = timed(a.fd_mode, ks, 1, serial=True)
+        extra["serial_plan"] = {"value": world * N * ks / el3, "unit": "Jacobians/s", "steps": ks,
+                                "ms_per_step": el3 / ks * 1e3, "kernel_ms_alone": k3, "plan_ms": p3}
 
     if rank == 0:
         n, nu = eng.n, eng.nu
@@ -270,7 +277,9 @@ def main():
                          "kernel_ms": kern_ms, "plan_ms": plan_ms,
                          "flops_per_launch_algorithmic": flops_alg, "flops_per_launch_executed_pmc": flops_exec,
                          "flops_executed_source": pmc_file if flops_exec else None,
-                         "frac_basis": "min(algorithmic, executed) / kernel_ms / peak",
+                         "frac_basis": "min(algorithmic, executed) / kernel_ms / peak; kernel_ms is the kernel's duration "
+                                       "inside the timed region (with the next step's plan launch sharing the chip when "
+                                       "pipelined; extra.serial_plan.kernel_ms_alone is the un-overlapped duration)",
                          "flops_per_unit": fpu, "flops_per_unit_in_kernel": fpu_kernel, "flops_source": how,
                          "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                  "bytes_per_unit": bytes_unit},
@@ -278,6 +287,9 @@ def main():
                                  % int(fpu / bytes_unit)},
             "units_with_bad_status": bad,
         }
+        if "serial_plan" in extra:
+            alone = extra["serial_plan"]["kernel_ms_alone"]
+            extra["serial_plan"]["roofline_frac_alone"] = flops_used / (alone * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS
         if extra:
             line["extra"] = extra
         if not a.no_cpu:

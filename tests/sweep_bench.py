@@ -21,7 +21,7 @@ import util
 
 PEAK = 78.6e12
 TW = C.CDLL(os.path.join(ROOT, "tests", "_build", "libhost_twin.so"))
-TW.twin_count_flops.restype = C.c_longlong
+TW.twin_count_flops_mt.restype = C.c_longlong
 dp = C.POINTER(C.c_double)
 
 
@@ -49,20 +49,23 @@ def flops_per_unit(eng, eid, q, v, c, fd_mode, eps=1e-6):
         tgt[p::R, col] += d
     qn, vn, r = np.empty_like(Q), np.empty_like(V), np.empty(len(Q))
     st = np.zeros(len(Q), dtype=np.uint32)
-    fl = TW.twin_count_flops(eid, 0, C.c_int64(len(Q)), Q.ctypes.data_as(dp), V.ctypes.data_as(dp), Cc.ctypes.data_as(dp),
-                             qn.ctypes.data_as(dp), vn.ctypes.data_as(dp), r.ctypes.data_as(dp),
-                             st.ctypes.data_as(C.POINTER(C.c_uint32)))
+    fl = TW.twin_count_flops_mt(eid, 0, C.c_int64(len(Q)), Q.ctypes.data_as(dp), V.ctypes.data_as(dp), Cc.ctypes.data_as(dp),
+                                qn.ctypes.data_as(dp), vn.ctypes.data_as(dp), r.ctypes.data_as(dp),
+                                st.ctypes.data_as(C.POINTER(C.c_uint32)), 16)
     return fl / n
 
 
 def constrained_share(eng, eid, q, v, c):
-    k = 0
+    """share of units with an active-candidate constraint at t0, and mean Newton passes (Hessian builds) of those"""
+    k, passes = 0, 0
     qa, fs, fc = np.zeros(eng.nv), np.zeros(eng.nv), np.zeros(eng.nv)
     it, na = C.c_int(), C.c_int()
     for i in range(len(q)):
         TW.twin_forward(eid, q[i].ctypes.data_as(dp), v[i].ctypes.data_as(dp), c[i].ctypes.data_as(dp), qa.ctypes.data_as(dp),
                         fs.ctypes.data_as(dp), fc.ctypes.data_as(dp), C.byref(it), C.byref(na))
         k += it.value > 0
+        passes += it.value
+    constrained_share.passes = passes / max(k, 1)
     return k / len(q)
 
 
@@ -70,14 +73,17 @@ def main():
     out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "sweep.md")
     os.makedirs(os.path.dirname(out_path), exist_ok=True)
     L = ["# Measurement sweep (one MI355X; S2 on-trajectory states; kernel time from HIP events, inputs resident in HBM)", "",
-         "| env | mode | units | single launch ms | plan + planned ms | Jacobians/s (faster of the two) | counted flops/unit | fp64 TFLOP/s | frac of 78.6 | constrained at t0 | bad status |",
-         "|---|---|---|---|---|---|---|---|---|---|---|"]
+         "| env | mode | units | single launch ms | plan + planned ms | Jacobians/s (faster of the two) | counted flops/unit | flops per dynamics evaluation | fp64 TFLOP/s | frac of 78.6 | constrained at t0 | Newton passes per constrained evaluation | bad status |",
+         "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
     cpu = ["", "| env | CPU oracle 1 thread (Jacobians/s) | 16 threads | GPU / 1 thread |", "|---|---|---|---|"]
     for eid, env in enumerate(util.ENVS):
         eng = FdEngine(env)
         N = 16384 if env == "Walker2dEnv" else 65536
         q, v, c = workloads.s2(eng, N, seed=0)
-        qh, vh, ch = (x[:48].cpu().numpy().copy() for x in (q, v, c))
+        nsample = 256 if env == "Walker2dEnv" else 2048
+        qh, vh, ch = (x[:nsample].cpu().numpy().copy() for x in (q, v, c))
+        evals = {"InvertedPendulumEnv": 48, "InvertedDoublePendulumEnv": 128, "SwimmerEnv": 520, "HopperEnv": 320,
+                 "Walker2dEnv": 2500, "HalfCheetahEnv": 250}[env]           # BASELINE.md section 2, forward mode
         share = constrained_share(eng, eid, *(x[:512].cpu().numpy().copy() for x in (q, v, c)))
         rate0 = None
         for fd_mode in (0, 1):
@@ -87,9 +93,11 @@ def main():
             fpu = flops_per_unit(eng, eid, qh, vh, ch, fd_mode)
             rate = N / ms * 1e3
             rate0 = rate0 or rate
-            L.append("| %s | %s | %d | %.3f | %.3f | %.3e | %.3e | %.2f | %.1f %% | %.0f %% | %d |" %
-                     (env[:-3], "central" if fd_mode else "forward (parity)", N, ms1, ms2, rate, fpu, rate * fpu / 1e12,
-                      100 * rate * fpu / PEAK, 100 * share, int((o["status"] != 0).sum())))
+            ev = evals * (2 * (eng.n + eng.nu) + 1) / (eng.n + eng.nu + 1) if fd_mode else evals
+            L.append("| %s | %s | %d | %.3f | %.3f | %.3e | %.3e | %.0f | %.2f | %.1f %% | %.0f %% | %.2f | %d |" %
+                     (env[:-3], "central" if fd_mode else "forward (parity)", N, ms1, ms2, rate, fpu, fpu / ev,
+                      rate * fpu / 1e12, 100 * rate * fpu / PEAK, 100 * share, constrained_share.passes,
+                      int((o["status"] != 0).sum())))
             print(L[-1], flush=True)
         orc = Oracle(env)
         n1 = {"Walker2dEnv": 256, "HalfCheetahEnv": 4096, "HopperEnv": 4096}.get(env, 16384)
@@ -101,6 +109,17 @@ def main():
         print(cpu[-1], flush=True)
     L += cpu
     eng = FdEngine("HalfCheetahEnv")
+    # S1 (reset-like) next to S2 for the headline env: BASELINE.md section 3
+    L += ["", "| HalfCheetah set | units | plan + planned ms | Jacobians/s | counted flops/unit forward | central | flops per evaluation | constrained at t0 | Newton passes per constrained evaluation |",
+          "|---|---|---|---|---|---|---|---|---|"]
+    for name, (qs, vs, cs) in (("S1 reset-like", workloads.s1(eng, 163840, seed=0)), ("S2 on-trajectory", workloads.s2(eng, 163840, seed=0))):
+        ms, _ = kernel_ms(eng, qs, vs, cs, 0, planned=True)
+        qh, vh, ch = (x[:2048].cpu().numpy().copy() for x in (qs, vs, cs))
+        f0, f1 = flops_per_unit(eng, 5, qh, vh, ch, 0), flops_per_unit(eng, 5, qh, vh, ch, 1)
+        share = constrained_share(eng, 5, *(x[:2048].cpu().numpy().copy() for x in (qs, vs, cs)))
+        L.append("| %s | 163840 | %.3f | %.3e | %.3e | %.3e | %.0f | %.0f %% | %.2f |" %
+                 (name, ms, 163840 / ms * 1e3, f0, f1, f0 / 250, 100 * share, constrained_share.passes))
+        print(L[-1], flush=True)
     L += ["", "| HalfCheetah forward, units per launch | single launch ms | plan + planned ms | Jacobians/s (faster) |", "|---|---|---|---|"]
     qa, va, ca = workloads.s2(eng, 1 << 18, seed=1)
     for k in range(8, 19, 2):
