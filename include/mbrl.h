@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MBRL_ABI_VERSION 6
+#define MBRL_ABI_VERSION 7
 
 /* per-unit status bits (replace mujoco-py's MujocoException / the reference's asserts,
  * backward.py:371,374) */
@@ -107,6 +107,23 @@ int mbrl_fd_jacobians_planned(const mbrl_model *m, int64_t N, const double *qpos
                               const double *ctrl_pert, double eps, int fd_mode, int nsteps, const void *plan,
                               int64_t plan_bytes, double *dsds, double *dsda, double *drds, double *drda,
                               uint32_t *status, void *hip_stream);
+
+/* The plan launch folded into step launches that run anyway.  In the reference the forward op's env step IS the nominal
+ * rollout calculate_gradients later receives (model/blocks/mujoco.py:20-31 -> mujoco/utils/backward.py:343); a batched
+ * rollout runs those same steps as mbrl_step launches, so it can record the plan while it goes:
+ *   mbrl_step_record     mbrl_step (same launch, same bits) that also leaves, for unit unit_offset + i of a plan made
+ *                        for plan_units units, the control-flow key of its rollout and its next state in `plan`
+ *                        (the N units of one time step of B episodes are units [t*B, t*B + B) of a time-major chunk);
+ *   mbrl_fd_plan_finish  once every unit of the plan has been recorded: takes the rewards [plan_units] the step launches
+ *                        wrote, writes the plan's header and sorts the units by key.
+ * The finished plan is what mbrl_fd_plan would have left for the same (state, action) units with nsteps = 1, and
+ * mbrl_fd_jacobians_planned runs on it unchanged -- no separate launch of nominal rollouts.  Same plan buffer rules as
+ * mbrl_fd_plan (mbrl_fd_plan_bytes(m, plan_units), 256-byte aligned, caller-owned). */
+int mbrl_step_record(const mbrl_model *m, int64_t N, const double *qpos, const double *qvel, const double *ctrl,
+                     double *qpos_next, double *qvel_next, double *reward, uint32_t *status, void *plan, int64_t plan_bytes,
+                     int64_t plan_units, int64_t unit_offset, void *hip_stream);
+int mbrl_fd_plan_finish(const mbrl_model *m, int64_t plan_units, const double *reward, void *plan, int64_t plan_bytes,
+                        void *hip_stream);
 
 /* NO COUNTERPART IN THE REFERENCE.  For callers that cannot allocate device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc) and so cannot bring the plan workspace mbrl_fd_plan wants: the same

@@ -120,7 +120,7 @@ struct WaveMap {
 #define MBRL_PLAN_SLOT(slot) (N - 1 - (slot))
 #endif
 constexpr int kKeyBits = 62;   // (3 bits x the last 10 mj_forward calls) of Lean::key, then the same of Lean::key2
-constexpr int PLAN_NONE = 0, PLAN_WRITE = 1, PLAN_READ = 2;
+constexpr int PLAN_NONE = 0, PLAN_WRITE = 1, PLAN_READ = 2, PLAN_RECORD = 3;   // RECORD: keys only (mbrl_step_record)
 constexpr unsigned ST_BADPLAN = MBRL_ST_BADPLAN;
 struct PlanHeader {
     unsigned long long magic;   // kPlanMagic
@@ -144,8 +144,13 @@ struct PlanLayout {
 
 // STEP_NAME only gives plain-step launches their own symbol in profiler output (the body does not use it,
 // so both instantiations are compiled from identical IR; tests/test_gpu_parity.py checks the bits).
+#ifdef MBRL_WAVES_PER_EU
+#define MBRL_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(MBRL_WAVES_PER_EU)))
+#else
+#define MBRL_KERNEL_ATTR
+#endif
 template <class M, bool STEP_NAME>
-__global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_skip, int nsteps, double eps, int mode,
+__global__ __launch_bounds__(kBlock) MBRL_KERNEL_ATTR void rollout_kernel(int64_t N, int frame_skip, int nsteps, double eps, int mode,
                                                           const double *__restrict__ qpos,
                                                           const double *__restrict__ qvel,
                                                           const double *__restrict__ ctrl,
@@ -251,11 +256,13 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_sk
         for (int j = 0; j < NV; j++) { o[j] = S.mem.ld(LY::OQ + j); o[NV + j] = S.mem.ld(LY::OV + j); }
         o[NS] = r;
         st = S.status;
-        if (plan_mode == PLAN_WRITE) {
+        if (plan_mode == PLAN_WRITE || plan_mode == PLAN_RECORD) {
+            // (the key segment starts at a fixed offset, so a step launch that records into a larger plan gets the
+            // buffer pointer advanced by its unit offset and needs to know nothing else about that plan)
             const PlanOffsets po(N, NS);
             reinterpret_cast<uint64_t *>(plan + po.key_in)[unit] =
                 (uint64_t(S.key & 0x3fffffffu) << 32) | uint64_t(S.key2 & 0x3fffffffu);
-            reinterpret_cast<uint32_t *>(plan + po.idx_in)[unit] = uint32_t(unit);
+            if (plan_mode == PLAN_WRITE) reinterpret_cast<uint32_t *>(plan + po.idx_in)[unit] = uint32_t(unit);
         }
     } else {
 #pragma unroll
@@ -306,6 +313,18 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(int64_t N, int frame_sk
     // status: OR over the unit's rollouts; a unit can live in two waves, so it is accumulated in HBM (zeroed by the host)
     if (status && live && st) atomicOr(&status[unit], st);
     MBRL_STAMP(3);
+}
+
+// mbrl_fd_plan_finish: header and identity order of a plan whose keys and nominal results were recorded by step launches.
+__global__ __launch_bounds__(256) void plan_finish_kernel(int64_t N, int nsteps, int frame_skip, int env_id, int ns,
+                                                           char *__restrict__ plan) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i == 0) {
+        PlanHeader *hd = reinterpret_cast<PlanHeader *>(plan);
+        hd->magic = kPlanMagic; hd->units = N; hd->nsteps = nsteps; hd->frame_skip = frame_skip; hd->env_id = env_id;
+        hd->pad = 0;
+    }
+    if (i < N) reinterpret_cast<uint32_t *>(plan + PlanOffsets(N, ns).idx_in)[i] = uint32_t(i);
 }
 
 // Backward recurrence of the op chain (mujoco.py:43-104): one thread per (episode, output lane).
@@ -624,6 +643,65 @@ int mbrl_fd_plan(const mbrl_model *m, int64_t N, const double *qpos, const doubl
         return fail(-10, "mbrl_fd_plan: copying next_state failed");
     if (reward && hipMemcpyAsync(reward, nom_r, sizeof(double) * size_t(N), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return fail(-10, "mbrl_fd_plan: copying reward failed");
+    return 0;
+}
+
+int mbrl_step_record(const mbrl_model *m, int64_t N, const double *qpos, const double *qvel, const double *ctrl,
+                     double *qpos_next, double *qvel_next, double *reward, uint32_t *status, void *plan, int64_t plan_bytes,
+                     int64_t plan_units, int64_t unit_offset, void *hip_stream) {
+    if (!m) return fail(-1, "mbrl_step_record: null model");
+    if (N < 0 || plan_units < 0 || unit_offset < 0) return fail(-6, "mbrl_step_record: negative size");
+    if (N == 0) return 0;
+    if (!qpos || !qvel || !ctrl || !qpos_next || !qvel_next || !plan) return fail(-1, "mbrl_step_record: null buffer");
+    if (unit_offset + N > plan_units) return fail(-6, "mbrl_step_record: units [offset, offset + N) must lie inside the plan");
+    if (plan_units > (int64_t(1) << 31)) return fail(-6, "mbrl_step_record: plan too large");
+    if (reinterpret_cast<uintptr_t>(plan) & 255) return fail(-7, "mbrl_step_record: the plan buffer must be 256-byte aligned");
+    if (hipSetDevice(m->device) != hipSuccess) return fail(-4, "mbrl_step_record: hipSetDevice failed");
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int ns = m->nq + m->nv;
+    PlanLayout L;
+    if (!plan_layout(plan_units, ns, st, L)) return fail(-10, "mbrl_step_record: sort size query failed");
+    if (plan_bytes < int64_t(L.total))
+        return fail(-8, "mbrl_step_record: plan buffer too small%s (need %lld bytes, see mbrl_fd_plan_bytes)", "", (long long)L.total);
+    char *w = static_cast<char *>(plan);
+    const PlanOffsets po(plan_units, ns);
+    double *nom_s = reinterpret_cast<double *>(w + po.nom_s) + unit_offset * ns;
+    int rc = 0;
+    // the launch is mbrl_step's; it also leaves s' in the plan's nominal segment and its key in the key segment
+    MBRL_DISPATCH(m->env_id, (rc = launch_rollouts<M>(m, N, MODE_STEP, qpos, qvel, ctrl, nullptr, 0.0, 1, nullptr, nullptr,
+                                                      nullptr, nullptr, nom_s, qpos_next, qvel_next, reward, status, st,
+                                                      w + sizeof(uint64_t) * size_t(unit_offset), PLAN_RECORD)));
+    if (rc) return fail(-10, "mbrl_step_record: clearing the status words failed");
+    return check_launch(m, "mbrl_step_record");
+}
+
+int mbrl_fd_plan_finish(const mbrl_model *m, int64_t plan_units, const double *reward, void *plan, int64_t plan_bytes,
+                        void *hip_stream) {
+    if (!m) return fail(-1, "mbrl_fd_plan_finish: null model");
+    if (plan_units < 0) return fail(-6, "mbrl_fd_plan_finish: negative size");
+    if (plan_units == 0) return 0;
+    if (!plan || !reward) return fail(-1, "mbrl_fd_plan_finish: null buffer");
+    if (plan_units > (int64_t(1) << 31)) return fail(-6, "mbrl_fd_plan_finish: plan too large");
+    if (reinterpret_cast<uintptr_t>(plan) & 255) return fail(-7, "mbrl_fd_plan_finish: the plan buffer must be 256-byte aligned");
+    if (hipSetDevice(m->device) != hipSuccess) return fail(-4, "mbrl_fd_plan_finish: hipSetDevice failed");
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int ns = m->nq + m->nv;
+    PlanLayout L;
+    if (!plan_layout(plan_units, ns, st, L)) return fail(-10, "mbrl_fd_plan_finish: sort size query failed");
+    if (plan_bytes < int64_t(L.total)) return fail(-8, "mbrl_fd_plan_finish: plan buffer too small");
+    char *w = static_cast<char *>(plan);
+    const PlanOffsets po(plan_units, ns);
+    hipLaunchKernelGGL(plan_finish_kernel, dim3((unsigned)((plan_units + 255) / 256)), dim3(256), 0, st, plan_units, 1,
+                       m->frame_skip, m->env_id, ns, w);
+    int rc = check_launch(m, "mbrl_fd_plan_finish");
+    if (rc) return rc;
+    if (hipMemcpyAsync(w + po.nom_r, reward, sizeof(double) * size_t(plan_units), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return fail(-10, "mbrl_fd_plan_finish: copying the rewards failed");
+    size_t tmp = L.sort_bytes;
+    if (rocprim::radix_sort_pairs(w + L.sort_tmp, tmp, reinterpret_cast<uint64_t *>(w + po.key_in),
+                                  reinterpret_cast<uint64_t *>(w + po.key_out), reinterpret_cast<uint32_t *>(w + po.idx_in),
+                                  reinterpret_cast<uint32_t *>(w + po.perm), size_t(plan_units), 0, kKeyBits, st) != hipSuccess)
+        return fail(-10, "mbrl_fd_plan_finish: sorting the units failed");
     return 0;
 }
 

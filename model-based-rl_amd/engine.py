@@ -19,13 +19,14 @@ class Plan:
     and the batch size its current plan was made for."""
 
     def __init__(self):
-        self.buf, self.units = None, -1
+        self.buf, self.units, self.capacity = None, -1, 0
 
     def reserve(self, engine, N):
         need = engine.plan_bytes(N)
         if self.buf is None or self.buf.numel() < need:
             self.buf = torch.empty(need, dtype=torch.uint8, device=engine.device)   # torch blocks are 512-byte aligned
             self.units = -1
+        self.capacity = max(self.capacity, int(N))
         return self.buf
 
 
@@ -103,6 +104,27 @@ class FdEngine:
         with torch.cuda.device(self.device):
             lib.check(self.L.mbrl_step(self.h, N, _ptr(qpos), _ptr(qvel), _ptr(ctrl), _ptr(qpos_next), _ptr(qvel_next),
                                        _ptr(reward), _ptr(status), self._stream()))
+
+    def step_record(self, qpos, qvel, ctrl, qpos_next, qvel_next, reward, status, plan, plan_units, unit_offset):
+        """step_into that also records these units' rollouts (keys, next states) as units [unit_offset, unit_offset + N)
+        of `plan`, a launch plan for plan_units units (mbrl_step_record): the batched rollout's own step launches are
+        the nominal rollouts of the linearisation that follows."""
+        N = qpos.shape[0]
+        buf = plan.buf
+        if buf is None or plan.capacity < plan_units:
+            raise lib.MbrlError("step_record: reserve the plan for %d units first" % plan_units)
+        with torch.cuda.device(self.device):
+            lib.check(self.L.mbrl_step_record(self.h, N, _ptr(qpos), _ptr(qvel), _ptr(ctrl), _ptr(qpos_next), _ptr(qvel_next),
+                                              _ptr(reward), _ptr(status), _ptr(buf), buf.numel(), int(plan_units),
+                                              int(unit_offset), self._stream()))
+
+    def plan_finish(self, plan, plan_units, reward):
+        """Header + unit order of a plan recorded by step_record launches (mbrl_fd_plan_finish); `reward` [plan_units]
+        is what those launches wrote.  fd_planned(..., plan=plan) runs on it."""
+        with torch.cuda.device(self.device):
+            lib.check(self.L.mbrl_fd_plan_finish(self.h, int(plan_units), _ptr(reward), _ptr(plan.buf), plan.buf.numel(),
+                                                 self._stream()))
+        plan.units = int(plan_units)
 
     def perturbed_policy_actions(self, qpos, qvel, policy, eps=1e-6, fd_mode=lib.FD_FORWARD):
         """Closed-loop mode (cfg.MODEL.POLICY.NETWORK, backward.py:418-419,460-461): the policy's action at every

@@ -66,13 +66,38 @@ class Linearisation:
         self.stream = engine.side_stream()
         self.next_t = 0
         self._recorded = False
+        self._chunk_plans = {}      # chunk start t0 -> Plan being recorded by the rollout's own step launches
         # the Jacobian buffers were allocated on the caller's stream and are written on the side stream: tell the
         # caching allocator, so that their blocks are not handed out again while a side-stream launch may still run
         for t in self.jac.values():
             t.record_stream(self.stream)
 
-    def submit(self, Q, V, A, t_done):
-        """Called on the rollout's stream after step t_done - 1 was enqueued: linearise the finished chunks."""
+    def _chunk(self, t):
+        t0 = (t // self.chunk) * self.chunk
+        return t0, min(self.H, t0 + self.chunk)
+
+    def recorder(self, t):
+        """(plan, plan_units, unit_offset) when the step launch of time t should record its rollouts into its chunk's
+        launch plan (FdEngine.step_record), else None.  The step launches ARE the nominal rollouts of the linearisation
+        (the reference's forward op hands calculate_gradients its next_state, model/blocks/mujoco.py:20-31), so a chunk
+        that will run the two-launch schedule needs no nominal launch of its own -- only the sort."""
+        t0, t1 = self._chunk(t)
+        units = (t1 - t0) * self.B
+        if not self.eng.known_schedule(units, self.fd_mode, 1, self.policy is not None):
+            return None
+        plan = self._chunk_plans.get(t0)
+        if plan is None:
+            cache = self.eng.__dict__.setdefault("_rollout_plans", {})
+            plan = cache.setdefault((t0, self.chunk), self.eng.new_plan())
+            plan.reserve(self.eng, units)
+            plan.buf.record_stream(self.stream)
+            plan.units = -1
+            self._chunk_plans[t0] = plan
+        return plan, units, (t - t0) * self.B
+
+    def submit(self, Q, V, A, t_done, R=None, S=None):
+        """Called on the rollout's stream after step t_done - 1 was enqueued: linearise the finished chunks.  R, S: the
+        rollout's reward / status buffers (needed for chunks whose plan the step launches recorded)."""
         if not self._recorded:      # the rollout's state / action buffers are read on the side stream
             for t in (Q, V, A):
                 t.record_stream(self.stream)
@@ -87,6 +112,17 @@ class Linearisation:
                 sl = slice(t0 * self.B, t1 * self.B)
                 out = {k: v[sl] for k, v in self.jac.items()}
                 e = self.eng
+                plan = self._chunk_plans.pop(t0, None)
+                if plan is not None:
+                    # the step launches of this chunk recorded keys and next states: finish the plan (sort), then the
+                    # perturbed rollouts only
+                    e.plan_finish(plan, (t1 - t0) * self.B, R[t0:t1].reshape(-1))
+                    out["status"].copy_(S[t0:t1].reshape(-1))
+                    out["reward"].copy_(R[t0:t1].reshape(-1))
+                    out["s_next"].copy_(torch.cat([Q[t0 + 1:t1 + 1], V[t0 + 1:t1 + 1]], dim=2).reshape(-1, e.n))
+                    e.fd_planned(Q[t0:t1].reshape(-1, e.nq), V[t0:t1].reshape(-1, e.nv), A[t0:t1].reshape(-1, e.nu), out,
+                                 eps=self.eps, fd_mode=self.fd_mode, policy=self.policy, plan=plan)
+                    continue
                 # schedule: the remembered choice for this size class (single launch until tune() has measured it) --
                 # the measurement blocks the host and must not run here, beside the rollout.  The plan, if any, is the
                 # side stream's own (FdEngine keeps one per stream).
@@ -186,9 +222,15 @@ def rollout_with_policy(engine, agent, model_policy, s0, horizon, linearise=None
         a = model_policy(torch.cat([Q[t], V[t]], dim=1).float()).double()
         acts.append(a)
         A[t].copy_(a.detach())
-        engine.step_into(Q[t], V[t], A[t], Q[t + 1], V[t + 1], R[t], S[t])
+        rec = lin.recorder(t) if lin is not None else None
+        if rec is not None:
+            engine.step_record(Q[t], V[t], A[t], Q[t + 1], V[t + 1], R[t], S[t], *rec)
+        else:
+            engine.step_into(Q[t], V[t], A[t], Q[t + 1], V[t + 1], R[t], S[t])
         if lin is not None:
-            lin.submit(Q, V, A, t + 1)
+            for buf in ((R, S) if t == 0 else ()):
+                buf.record_stream(lin.stream)
+            lin.submit(Q, V, A, t + 1, R, S)
     states, rewards, status = _episode_major(Q, V, R, S)
     agent.set_step_idx(horizon)
     if lin is not None:

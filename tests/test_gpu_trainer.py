@@ -211,3 +211,58 @@ def test_flagged_episodes_are_masked_not_fatal():
         grads[poison] = [p.grad.clone() for p in policy.parameters() if p.grad is not None]
     for a, b in zip(grads[False], grads[True]):
         assert torch.isfinite(b).all() and torch.allclose(a, b, rtol=1e-12, atol=1e-14)
+
+
+def test_step_record_builds_the_plan_mbrl_fd_plan_would():
+    """mbrl_step_record + mbrl_fd_plan_finish (the plan launch folded into step launches that run anyway): the recorded
+    plan drives mbrl_fd_jacobians_planned to the bits of the ordinary two-launch schedule, and the step outputs are
+    mbrl_step's."""
+    import torch
+    import mbrl_amd  # noqa: F401
+    from mbrl_amd import workloads
+    from mbrl_amd.engine import FdEngine
+    e = FdEngine("HalfCheetahEnv")
+    B, T = 700, 3
+    q, v, c = workloads.s2(e, B * T, seed=4, horizon=8)
+    ref = e.fd_jacobians(q, v, c, planned=True)
+    qn, vn, r, st = e.step(q, v, c)
+    plan = e.new_plan(B * T)
+    Q1, V1 = torch.empty_like(q), torch.empty_like(v)
+    R, S = torch.empty(B * T, dtype=torch.float64, device="cuda"), torch.empty(B * T, dtype=torch.int32, device="cuda")
+    for t in range(T):                                   # three "time steps" of 700 "episodes" each
+        sl = slice(t * B, (t + 1) * B)
+        e.step_record(q[sl], v[sl], c[sl], Q1[sl], V1[sl], R[sl], S[sl], plan, B * T, t * B)
+    assert torch.equal(Q1, qn) and torch.equal(V1, vn) and torch.equal(R, r) and torch.equal(S, st)
+    e.plan_finish(plan, B * T, R)
+    out = e.new_outputs(B * T)
+    out["status"].copy_(S)
+    e.fd_planned(q, v, c, out, plan=plan)
+    torch.cuda.synchronize()
+    for k in ("dsds", "dsda", "drds", "drda", "status"):
+        assert torch.equal(ref[k], out[k]), k
+    from mbrl_amd import lib
+    with pytest.raises(lib.MbrlError):
+        e.step_record(q[:B], v[:B], c[:B], Q1[:B], V1[:B], R[:B], S[:B], plan, B * T, 2 * B + 1)     # sticks out of the plan
+
+
+def test_recorded_plans_train_bit_for_bit(tmp_path):
+    """The trainer's overlapped linearisation with plans recorded by its own step launches (no nominal launch) trains
+    the parameters the linearisation inside loss.backward() trains."""
+    import torch
+    from mbrl_amd.engine import FdEngine
+    res = {}
+    for recorded in (False, True):
+        cfg = _cfg("HalfCheetahEnv", B=40, H=6, epochs=3, MODEL__FD_OVERLAP_STEPS=4 if recorded else 0)
+        if recorded:       # pretend the schedule measurement chose the two-launch schedule for every size class
+            orig = FdEngine.known_schedule
+            FdEngine.known_schedule = lambda self, *a, **k: True
+        try:
+            agent, rows, d = _train(cfg, tmp_path, "rec%d" % recorded)
+        finally:
+            if recorded:
+                FdEngine.known_schedule = orig
+        if recorded:
+            assert "_rollout_plans" in agent.engine.__dict__ and len(agent.engine._rollout_plans) == 2
+        res[recorded] = {k: v.cpu() for k, v in agent.policy_net.state_dict().items()}
+    for k in res[False]:
+        assert torch.equal(res[False][k], res[True][k]), k
