@@ -242,35 +242,45 @@ class FdEngine:
         """True / False once tune_schedule has measured this size class, None before."""
         return self._schedule.get(self.schedule_key(N, fd_mode, nsteps, closed_loop))
 
-    def _faster_schedule(self, qpos, qvel, ctrl, ctrl_pert, eps, fd_mode, nsteps, o):
+    def _faster_schedule(self, qpos, qvel, ctrl, ctrl_pert, eps, fd_mode, nsteps, o, recorded=False):
         """Which of the two schedules is faster for this model, mode and batch size?  They produce the same bits, so
         the choice is made by running both once on the caller's inputs (first call per size class only) and kept.
         The plan pays off when the linearisation is long against one latency-bound launch of nominal rollouts:
-        HalfCheetah from ~3e4 units (forward) -- not for the pendulums, nor for small batches."""
+        HalfCheetah from ~3e4 units (forward) -- not for the pendulums, nor for small batches.  recorded: the caller's
+        step launches record the plan (step_record), so the two-launch schedule costs only the sort + the perturbed
+        rollouts."""
         N = qpos.shape[0]
         key = self.schedule_key(N, fd_mode, nsteps, ctrl_pert is not None)
         if key not in self._schedule:
             ms = {}
+            plan = self._stream_plan()
             for planned in (False, True):
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                if planned and recorded:
+                    self.fd_plan(qpos, qvel, ctrl, nsteps, o, plan=plan)
                 for rep in range(2):            # the first run warms up (plan buffer, code)
                     if rep:
                         ev[0].record(torch.cuda.current_stream(self.device))
-                    self.fd_jacobians(qpos, qvel, ctrl, eps, fd_mode, nsteps, o, ctrl_pert=ctrl_pert, planned=planned)
+                    if planned and recorded:
+                        self.plan_finish(plan, N, o["reward"])
+                        self.fd_planned(qpos, qvel, ctrl, o, eps, fd_mode, nsteps, ctrl_pert=ctrl_pert, plan=plan)
+                    else:
+                        self.fd_jacobians(qpos, qvel, ctrl, eps, fd_mode, nsteps, o, ctrl_pert=ctrl_pert, planned=planned)
                 ev[1].record(torch.cuda.current_stream(self.device))
                 ev[1].synchronize()
                 ms[planned] = ev[0].elapsed_time(ev[1])
             self._schedule[key] = ms[True] < ms[False]
         return self._schedule[key]
 
-    def tune_schedule(self, qpos, qvel, ctrl, eps=1e-6, fd_mode=lib.FD_FORWARD, nsteps=1, policy=None, ctrl_pert=None):
+    def tune_schedule(self, qpos, qvel, ctrl, eps=1e-6, fd_mode=lib.FD_FORWARD, nsteps=1, policy=None, ctrl_pert=None,
+                      recorded=False):
         """Measure both schedules once for this size class on the CURRENT stream (host-blocking: call it at warm-up,
         never from a stream that is meant to run beside another one) and remember the faster."""
         qpos, qvel, ctrl, ctrl_pert = self._fd_args(qpos, qvel, ctrl, eps, fd_mode, policy, ctrl_pert)
         N = qpos.shape[0]
         if N < 1024:
             return False
-        return self._faster_schedule(qpos, qvel, ctrl, ctrl_pert, eps, fd_mode, nsteps, self.new_outputs(N))
+        return self._faster_schedule(qpos, qvel, ctrl, ctrl_pert, eps, fd_mode, nsteps, self.new_outputs(N), recorded)
 
     def fd_jacobians(self, qpos, qvel, ctrl, eps=1e-6, fd_mode=lib.FD_FORWARD, nsteps=1, out=None, policy=None,
                      ctrl_pert=None, planned=None, plan=None):

@@ -6,6 +6,8 @@ procedure B*H times.  Here: H launches of the step kernel advance all B episodes
 launch of the FD kernel linearises all B*H stored (s_t, a_t), and one scan kernel runs the backward
 recurrence of the op chain.
 """
+import os
+
 import torch
 
 from . import lib
@@ -83,6 +85,8 @@ class Linearisation:
         that will run the two-launch schedule needs no nominal launch of its own -- only the sort."""
         t0, t1 = self._chunk(t)
         units = (t1 - t0) * self.B
+        if os.environ.get("MBRL_NO_STEP_RECORD"):      # measurement knob (tools/train_throughput.py)
+            return None
         if not self.eng.known_schedule(units, self.fd_mode, 1, self.policy is not None):
             return None
         plan = self._chunk_plans.get(t0)
@@ -136,7 +140,7 @@ class Linearisation:
         if n >= 1024 and e.known_schedule(n, self.fd_mode, 1, self.policy is not None) is None:
             k = min(self.chunk, self.H)
             e.tune_schedule(Q[:k].reshape(-1, e.nq), V[:k].reshape(-1, e.nv), A[:k].reshape(-1, e.nu), eps=self.eps,
-                            fd_mode=self.fd_mode, policy=self.policy)
+                            fd_mode=self.fd_mode, policy=self.policy, recorded=True)
 
     def __del__(self):
         # the side stream reads buffers this object keeps alive (lin.keep): never let them return to the allocator
