@@ -68,7 +68,7 @@ def launch_ranks(n):
 def recorded(pattern):
     """Newest committed profiles/rNN_<pattern>.json (rocprofv3 PMC passes of this command, one counter group per run),
     or None."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + pattern + ".json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*" + pattern + ".json")))
     return (json.load(open(files[-1])), os.path.basename(files[-1])) if files else (None, None)
 
 
