@@ -26,22 +26,3 @@ for B in [int(x) for x in os.environ.get("BATCHES", "1024,4096,16384").split(","
     base = min(run(B, 3) for _ in range(2))
     per = (min(run(B, 13) for _ in range(2)) - base) / 10
     print("B %6d: %.1f ms per epoch, %.2f M env steps/s = linearised (s, a)/s" % (B, per * 1e3, B * 40 / per / 1e6), flush=True)
-sys.exit(0)
-for B in [int(x) for x in os.environ.get("BATCHES", "64,1024,4096,16384").split(",")]:
-    for epochs in (3, 13):       # the difference of the two runs is 10 steady-state epochs
-        cfg = config.get_cfg_defaults()
-        cfg.merge_from_file(os.path.join(os.path.dirname(__file__), "..", "configs", "half_cheetah.yaml"))
-        cfg.merge_from_list(["MODEL.BATCH_SIZE", str(B), "MODEL.EPOCHS", str(epochs), "LOG.PERIOD", "1000",
-                             "MODEL.FD_OVERLAP_STEPS", os.environ.get("OVERLAP", "8")])
-        cfg.freeze()
-        d = tempfile.mkdtemp()
-        lg = logging.getLogger("quiet%d_%d" % (B, epochs)); lg.setLevel(logging.ERROR)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        trainer.do_training(cfg, lg, d, d, d, 1)
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        if epochs == 3:
-            base = dt
-        else:
-            per = (dt - base) / 10
-            print("B %6d: %.1f ms per epoch, %.2f M env steps/s, %.2f M linearised (s, a)/s" %
-                  (B, per * 1e3, B * 40 / per / 1e6, B * 40 / per / 1e6), flush=True)
