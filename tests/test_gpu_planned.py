@@ -221,3 +221,28 @@ def test_two_streams_linearise_side_by_side_with_their_own_plans():
     od = e.fd_jacobians(qa, va, ca, planned="cached")
     assert e.known_schedule(2500) is None and all(torch.equal(ref_a[k], od[k]) for k in ref_a)
     assert e.tune_schedule(qa, va, ca) in (True, False) and e.known_schedule(2500) is not None
+
+
+def test_full_bench_size_properties():
+    """BASELINE.json's full size (4096 x 40 = 163 840 HalfCheetah units), through size-independent properties: the
+    two-launch schedule equals the single launch bit for bit, the nominal rollouts equal mbrl_step bit for bit (the
+    reference's assert, backward.py:371,374), a second launch reproduces the bits, no unit is flagged, and the
+    action columns of units with saturated controls vanish exactly."""
+    import torch
+    from mbrl_amd import workloads
+    e = _eng("HalfCheetahEnv")
+    N = 4096 * 40
+    q, v, c = workloads.s2(e, N, seed=0, horizon=40)
+    c = c.clone()
+    c[::97] = torch.sign(c[::97]) * 1.25                      # every 97th unit: all controls beyond ctrlrange
+    a = e.fd_jacobians(q, v, c, planned=False)
+    b = e.fd_jacobians(q, v, c, planned=True)
+    b2 = e.fd_jacobians(q, v, c, planned=True)
+    qn, vn, r, st = e.step(q, v, c)
+    torch.cuda.synchronize()
+    for k in a:
+        assert torch.equal(a[k], b[k]) and torch.equal(b[k], b2[k]), k
+    assert torch.equal(torch.cat([qn, vn], dim=1), b["s_next"]) and torch.equal(r, b["reward"])
+    assert int((b["status"] != 0).sum()) == 0 and int((st != 0).sum()) == 0
+    assert float(b["dsda"][::97].abs().max()) == 0.0 and float(b["dsda"].abs().max()) > 0.0
+    assert bool(torch.isfinite(b["dsds"]).all())
