@@ -135,10 +135,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = world > 1
+    # MBRL_DIST_BACKEND=gloo: rehearsal with more ranks than GPUs (ranks share GPUs; RCCL needs a GPU per rank)
+    backend = os.environ.get("MBRL_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     if dist:
         import torch.distributed as td
-        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            td.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            td.init_process_group(backend)
 
     import mbrl_amd  # noqa: F401
     from mbrl_amd import workloads

@@ -67,13 +67,16 @@ def init_distributed(backend=None):
     if world <= 1:
         return None
     local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
-    if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend is None:     # MBRL_DIST_BACKEND=gloo: ranks that share one GPU (tests on a one-GPU box); RCCL needs a GPU per rank
+        backend = os.environ.get("MBRL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         return "cuda:%d" % local
     dist.init_process_group(backend)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+        return "cuda:%d" % local
     return None
 
 

@@ -266,3 +266,57 @@ def test_recorded_plans_train_bit_for_bit(tmp_path):
         res[recorded] = {k: v.cpu() for k, v in agent.policy_net.state_dict().items()}
     for k in res[False]:
         assert torch.equal(res[False][k], res[True][k]), k
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("weights", ["average", "prioritise"])
+def test_two_ranks_on_the_gpu_train_like_one(weights, tmp_path):
+    """The command line under torch.distributed with the REAL engine: two ranks (fresh processes, as `--gpus 2` starts
+    them; both bound to this box's one GPU, so the process group is gloo -- RCCL wants a GPU per rank) shard 6 episodes
+    3 + 3, all-reduce the gradient, rank 0 writes the files; the trained parameters equal the single-process run's."""
+    import socket
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    opts = ["--config-file", os.path.join(root, "configs", "half_cheetah.yaml"), "--opts", "MODEL.EPOCHS", "3",
+            "MODEL.BATCH_SIZE", "6", "MODEL.POLICY.MAX_HORIZON_STEPS", "5", "MODEL.POLICY.GRAD_WEIGHTS", weights,
+            "MODEL.POLICY.INITIAL_SD", "0.2", "MODEL.RANDOM_SEED", "5", "LOG.CHECKPOINT_PERIOD", "2",
+            "OUTPUT.DIR", str(tmp_path)]
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    subprocess.check_call([sys.executable, "-m", "mbrl_amd.main"] + opts + ["OUTPUT.NAME", "one"], env=env, cwd=root,
+                          stdout=subprocess.DEVNULL)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [subprocess.Popen([sys.executable, "-m", "mbrl_amd.main"] + opts + ["OUTPUT.NAME", "two"], cwd=root,
+                              stdout=subprocess.DEVNULL,
+                              env=dict(env, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                                       MASTER_PORT=str(port), MBRL_DIST_BACKEND="gloo")) for r in range(2)]
+    assert [p.wait(timeout=240) for p in procs] == [0, 0]
+    one = torch.load(tmp_path / "HalfCheetahEnv" / "one" / "weights" / "iter_2.pth", weights_only=True)
+    two = torch.load(tmp_path / "HalfCheetahEnv" / "two" / "weights" / "iter_2.pth", weights_only=True)
+    assert sorted(os.listdir(tmp_path / "HalfCheetahEnv" / "two" / "results")) == ["output_0"]
+    for k in one:
+        assert torch.allclose(one[k].cpu(), two[k].cpu(), rtol=1e-9, atol=1e-12), k
+
+
+@pytest.mark.timeout(300)
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` starts two fresh ranks by itself and rank 0 prints ONE JSON line with n_gpus = 2 and
+    the aggregate rate (rehearsed on this box's one GPU with the gloo process group; the driver's 8-GPU run uses RCCL)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MBRL_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--units", "8192", "--no-cpu", "--no-extra"], env=env, cwd=root, stdout=subprocess.PIPE,
+                         timeout=240, check=True).stdout.decode()
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and line["units_with_bad_status"] == 0
+    assert line["config"]["units_per_gpu"] == 8192 and abs(line["value"] - 2 * 8192 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
