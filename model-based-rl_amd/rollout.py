@@ -61,8 +61,9 @@ class Linearisation:
     step is done only the last chunk is outstanding.  The reference has no counterpart (its FD runs inside
     loss.backward(), trainer.py:77); the results are the same Jacobians."""
 
-    def __init__(self, engine, B, H, eps, fd_mode, policy, chunk):
+    def __init__(self, engine, B, H, eps, fd_mode, policy, chunk, nsteps=1):
         self.eng, self.B, self.H, self.eps, self.fd_mode, self.policy = engine, B, H, eps, fd_mode, policy
+        self.nsteps = int(nsteps)   # cfg.MODEL.NSTEPS_FOR_BACKWARD (backward.py:359): env steps per FD rollout
         self.chunk = max(1, int(chunk))
         self.jac = engine.new_outputs(B * H)
         self.stream = engine.side_stream()
@@ -86,6 +87,8 @@ class Linearisation:
         t0, t1 = self._chunk(t)
         units = (t1 - t0) * self.B
         if os.environ.get("MBRL_NO_STEP_RECORD"):      # measurement knob (tools/train_throughput.py)
+            return None
+        if self.nsteps != 1:         # a step launch is the nominal rollout of a ONE-env-step linearisation only
             return None
         if not self.eng.known_schedule(units, self.fd_mode, 1, self.policy is not None):
             return None
@@ -131,16 +134,17 @@ class Linearisation:
                 # the measurement blocks the host and must not run here, beside the rollout.  The plan, if any, is the
                 # side stream's own (FdEngine keeps one per stream).
                 e.fd_jacobians(Q[t0:t1].reshape(-1, e.nq), V[t0:t1].reshape(-1, e.nv), A[t0:t1].reshape(-1, e.nu),
-                               eps=self.eps, fd_mode=self.fd_mode, out=out, policy=self.policy, planned="cached")
+                               eps=self.eps, fd_mode=self.fd_mode, nsteps=self.nsteps, out=out, policy=self.policy,
+                               planned="cached")
 
     def tune(self, Q, V, A):
         """Once per size class, on the caller's stream with the side stream drained (RolloutRewards.backward calls it
         after wait()): measure which schedule is faster for a chunk of this rollout, for the following epochs."""
         e, n = self.eng, min(self.chunk, self.H) * self.B
-        if n >= 1024 and e.known_schedule(n, self.fd_mode, 1, self.policy is not None) is None:
+        if n >= 1024 and e.known_schedule(n, self.fd_mode, self.nsteps, self.policy is not None) is None:
             k = min(self.chunk, self.H)
             e.tune_schedule(Q[:k].reshape(-1, e.nq), V[:k].reshape(-1, e.nv), A[:k].reshape(-1, e.nu), eps=self.eps,
-                            fd_mode=self.fd_mode, policy=self.policy, recorded=True)
+                            fd_mode=self.fd_mode, nsteps=self.nsteps, policy=self.policy, recorded=self.nsteps == 1)
 
     def __del__(self):
         # the side stream reads buffers this object keeps alive (lin.keep): never let them return to the allocator
@@ -167,7 +171,8 @@ class RolloutRewards(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, actions, s0, engine, states, rewards, grad_weights, eps, fd_mode, policy, raise_on_status, lin=None,
-                shard=None):
+                shard=None, nsteps=1):
+        ctx.nsteps = int(nsteps)  # cfg.MODEL.NSTEPS_FOR_BACKWARD
         ctx.engine, ctx.gw, ctx.eps, ctx.fd_mode, ctx.policy, ctx.chk = engine, grad_weights, eps, fd_mode, policy, raise_on_status
         ctx.shard = shard        # (first episode, episodes of the whole batch) of a sharded run, or None
         ctx.lin = lin            # Linearisation already under way on the side stream (rollout_with_policy), or None
@@ -189,7 +194,7 @@ class RolloutRewards(torch.autograd.Function):
         else:
             s = states[:, :H].reshape(B * H, eng.n)
             jac = eng.fd_jacobians(s[:, :eng.nq], s[:, eng.nq:], actions.reshape(B * H, nu), eps=ctx.eps,
-                                   fd_mode=ctx.fd_mode, policy=ctx.policy)
+                                   fd_mode=ctx.fd_mode, nsteps=ctx.nsteps, policy=ctx.policy)
         if ctx.chk:
             bad = int((jac["status"] != 0).sum())
             if bad:
@@ -208,7 +213,7 @@ class RolloutRewards(torch.autograd.Function):
             da = da.permute(1, 0, 2)
         else:
             da, ds0 = eng.vjp_scan(jac, c.contiguous(), ctx.gw, shard=ctx.shard)
-        return da, ds0, None, None, None, None, None, None, None, None, None, None
+        return da, ds0, None, None, None, None, None, None, None, None, None, None, None
 
 
 def rollout_with_policy(engine, agent, model_policy, s0, horizon, linearise=None):

@@ -99,9 +99,10 @@ def do_training(cfg, logger, output_results_dir, output_rec_dir, output_weights_
             overlap = int(cfg.MODEL.get("FD_OVERLAP_STEPS", 4))     # 0: linearise inside loss.backward(), as the reference
             states, actions, rewards, status, lin = rollout.rollout_with_policy(
                 eng, agent, policy, s0, H,
-                linearise=dict(eps=eps, fd_mode=fd_mode, policy=fd_policy, chunk=overlap) if overlap > 0 else None)
+                linearise=dict(eps=eps, fd_mode=fd_mode, policy=fd_policy, chunk=overlap,
+                               nsteps=int(cfg.MODEL.NSTEPS_FOR_BACKWARD)) if overlap > 0 else None)
             r = rollout.RolloutRewards.apply(actions, s0, eng, states, rewards, cfg.MODEL.POLICY.GRAD_WEIGHTS,
-                                             eps, fd_mode, fd_policy, False, lin, (lo, B))
+                                             eps, fd_mode, fd_policy, False, lin, (lo, B), int(cfg.MODEL.NSTEPS_FOR_BACKWARD))
             batch_loss[:] = -r
             # A step the simulator flagged (MBRL_ST_*: non-finite state, solver at its iteration cap, ...) ends that
             # episode's contribution: its loss from there on is NaN, which `optimize` turns into zero loss and zero

@@ -320,3 +320,20 @@ def test_bench_starts_its_own_ranks():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and line["units_with_bad_status"] == 0
     assert line["config"]["units_per_gpu"] == 8192 and abs(line["value"] - 2 * 8192 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
+
+
+@pytest.mark.parametrize("overlap", [0, 4])
+def test_fused_schedule_honours_nsteps_for_backward(overlap, tmp_path):
+    """cfg.MODEL.NSTEPS_FOR_BACKWARD = 2 (backward.py:359,377-383: every FD rollout runs two env steps): the fused
+    schedule trains like the op-by-op graph, whose gradient function reads the key itself."""
+    import torch
+    res = {}
+    for path in ("fused", "ops"):
+        cfg = _cfg("InvertedDoublePendulumEnv", MODEL__ENGINE_PATH=path, MODEL__NSTEPS_FOR_BACKWARD=2,
+                   MODEL__FD_OVERLAP_STEPS=overlap)
+        agent, rows, d = _train(cfg, tmp_path, "%s%d" % (path, overlap))
+        res[path] = {k: v.cpu() for k, v in agent.policy_net.state_dict().items()}
+    one = _train(_cfg("InvertedDoublePendulumEnv", MODEL__FD_OVERLAP_STEPS=overlap), tmp_path, "n1_%d" % overlap)[0]
+    for k in res["fused"]:
+        assert torch.allclose(res["fused"][k], res["ops"][k], rtol=1e-6, atol=1e-9), k
+    assert any(not torch.allclose(res["fused"][k], v.cpu(), rtol=1e-6, atol=1e-9) for k, v in one.policy_net.state_dict().items())
