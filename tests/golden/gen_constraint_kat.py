@@ -276,6 +276,15 @@ class Sys:
         R, info = self.rows(q, v)
         if not R:
             return a0, M, info, 0
+        merged = []                                  # identical rows (the pyramid's two `n` rows): one row, D summed
+        for Jr, ar, Dr in R:
+            for mrow in merged:
+                if np.array_equal(mrow[0], Jr) and mrow[1] == ar:
+                    mrow[2] += Dr
+                    break
+            else:
+                merged.append([Jr, ar, Dr])
+        R = merged
         J = np.array([r[0] for r in R]); aref = np.array([r[1] for r in R]); D = np.array([r[2] for r in R])
         found = []
         for mask in itertools.product((False, True), repeat=len(R)):
@@ -386,7 +395,71 @@ def fluid_forces(S, q, v):
 
 
 # ------------------------------------------------------------------------------------------ cases
+def multi_contact():
+    """(ii'') several capsule ends on the floor at once (both ends of Hopper's foot, the two feet of Walker2d and
+    HalfCheetah): 2-3 contacts = 6-9 distinct pyramid rows coupled through J M^-1 J^T, enumerated like the rest.
+    Written to kat_constraints_multi.npz."""
+    rng = np.random.default_rng(23)
+    out = {}
+    U, W = LK.U, LK.W_
+    for env in ("HopperEnv", "Walker2dEnv", "HalfCheetahEnv"):
+        S = Sys(env)
+        recs = []
+
+        def heights(q):
+            hs = []
+            for b, g, gp in S.geom_list():
+                for end in (g["a"], g["b"]):
+                    e, _ = S.point(q, b, (end[U], end[W]))
+                    hs.append(e[1] - S.xp["floor"]["z"] - gp["radius"])
+            return np.sort(hs)
+
+        tries = 0
+        while len(recs) < 8 and tries < 200:
+            tries += 1
+            q = np.array([j["ref"] for j in S.joints]) + rng.uniform(-0.06, 0.06, S.nv)
+            for i, j in enumerate(S.joints):
+                if j["limited"]:
+                    lo, hi = j["range"]
+                    q[i] = min(max(q[i], lo + 0.02), hi - 0.02)
+            lo_p, hi_p = q[2] - 0.6, q[2] + 0.6           # pitch that puts the two lowest ends at the same height
+            gap = lambda p: (lambda h: h[1] - h[0])(heights(np.concatenate([q[:2], [p], q[3:]])))
+            ps = np.linspace(lo_p, hi_p, 61)
+            gs = [gap(p) for p in ps]
+            k = int(np.argmin(gs))
+            a_, b_ = ps[max(k - 1, 0)], ps[min(k + 1, 60)]
+            for _ in range(40):                           # golden-section style shrink on the (V-shaped) gap
+                m1, m2 = a_ + 0.382 * (b_ - a_), a_ + 0.618 * (b_ - a_)
+                if gap(m1) < gap(m2):
+                    b_ = m2
+                else:
+                    a_ = m1
+            q[2] = 0.5 * (a_ + b_)
+            h = heights(q)
+            margin = max(S.xp["floor"]["margin"], S.gparams[0]["margin"])
+            width = 0.5 * (S.xp["floor"]["solimp"][2] + S.gparams[0]["solimp"][2])
+            q[1] += -h[0] + margin - rng.uniform(0.2, 1.2) * width
+            v = 0.5 * rng.standard_normal(S.nv)
+            v[0] += rng.uniform(-1.5, 1.5)
+            c = rng.uniform(-1, 1, S.nu)
+            R, info = S.rows(q, v)
+            ncon = sum(1 for i in info if i[0] == "floor")
+            if ncon < 2 or ncon > 3 or any(i[0] not in ("floor",) for i in info):
+                continue
+            a, M, info, nact = S.qacc(q, v, c)
+            q1, v1 = S.step(q, v, c)
+            recs.append(dict(q=q, v=v, c=c, qacc=a, q1=q1, v1=v1, nactive=nact, dof=ncon))
+        tag = "multi_" + env[:-3].lower()
+        for k in recs[0]:
+            out[tag + "_" + k] = np.array([r[k] for r in recs])
+        print("%-34s %3d vectors  contacts %s  active merged rows %s" % (
+            tag, len(recs), sorted({int(r["dof"]) for r in recs}), sorted({int(r["nactive"]) for r in recs})), flush=True)
+    np.savez(os.path.join(HERE, "kat_constraints_multi.npz"), **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "multi":
+        return multi_contact()
     rng = np.random.default_rng(11)
     out = {}
 

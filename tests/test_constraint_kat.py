@@ -6,7 +6,8 @@ files, the smooth dynamics come from an autodiff Lagrangian, and the constrained
 active sets of the convex problem (no Newton iteration, no line search).  They cover: every joint limit of every model
 on both sides, inside and beyond the impedance ramp, with refsafe (InvertedPendulum: timeconst 0.02 < 2 dt) and a
 non-zero limit margin (InvertedDoublePendulum slider); one capsule end on the floor with pyramidal friction and a
-sliding velocity (Hopper, Walker2d, HalfCheetah: 0, 1, 3 or 4 rows active at the solution); a frictionless
+sliding velocity (Hopper, Walker2d, HalfCheetah: 0, 1, 3 or 4 rows active at the solution); two or three capsule ends
+on the floor at once (both ends of Hopper's foot, two feet of Walker2d / HalfCheetah: up to 9 coupled rows); a frictionless
 capsule/capsule row (Hopper foot against thigh/torso); Swimmer's inertia-box fluid forces.  The MuJoCo rules each group
 encodes are listed in the generator's header and in DESIGN.md section 2; MuJoCo itself stays unavailable offline.
 Tolerance: 1e-9 relative on qacc (the closed form goes through numpy solves of systems with condition ~1e6), 1e-10
@@ -20,8 +21,9 @@ import pytest
 import util
 from oracle import Oracle
 
-G = np.load(os.path.join(os.path.dirname(__file__), "golden", "kat_constraints.npz"))
-GROUPS = sorted({k.rsplit("_", 1)[0] for k in G.files if k.endswith("_qacc")})
+G = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "kat_constraints.npz")))
+G.update(np.load(os.path.join(os.path.dirname(__file__), "golden", "kat_constraints_multi.npz")))   # 2-3 contacts at once
+GROUPS = sorted({k.rsplit("_", 1)[0] for k in G if k.endswith("_qacc")})
 ENV_OF = {e[:-3].lower(): e for e in util.ENVS}
 dp = C.POINTER(C.c_double)
 
@@ -35,7 +37,8 @@ def _rel(a, b):
 
 
 def test_fixture_covers_what_it_claims():
-    assert {g.split("_")[0] for g in GROUPS} == {"limit", "floor", "pair", "fluid"}
+    assert {g.split("_")[0] for g in GROUPS} == {"limit", "floor", "pair", "fluid", "multi"}
+    assert all(G[g + "_dof"].min() >= 2 for g in GROUPS if g.startswith("multi_"))        # 2-3 simultaneous contacts
     assert len([g for g in GROUPS if g.startswith("limit_")]) == 6
     for g in GROUPS:
         if not g.startswith("fluid"):
@@ -50,7 +53,7 @@ def test_oracle_forward_matches_closed_form(group):
         f = o.forward(q, v, c)
         assert f["rc"] == 0
         assert _rel(f["qacc"], a) < 1e-9, (group, _rel(f["qacc"], a))
-        assert int((f["efc_force"] > 0).sum()) == int(na) or group.startswith("floor_")   # (n, n) rows tie in the pyramid
+        assert int((f["efc_force"] > 0).sum()) == int(na) or group.startswith(("floor_", "multi_"))   # (n, n) rows tie
     if group == "fluid_swimmer":
         for q, v, c, Qf in zip(G[group + "_q"], G[group + "_v"], G[group + "_c"], G[group + "_qfrc_fluid"]):
             f = o.forward(q, v, c)
