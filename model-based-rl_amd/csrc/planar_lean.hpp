@@ -1168,7 +1168,7 @@ struct Lean {
             return false;
         };
         // How many iterations run as straight-line code before the loop (the usual solve is pass, step, closing pass).
-        // Same arithmetic either way; measured per model (gpurun_out/ab_peel.txt, 65 536 units): Hopper gains 6 % with
+        // Same arithmetic either way; measured per model (profiles/r02_experiments.md, 65 536 units): Hopper gains 6 % with
         // two peeled iterations, HalfCheetah and Walker2d lose 2-4 % (larger kernels: the copies cost more than the
         // loop's register shuffle), so only Hopper peels.
         constexpr int kPeel = (M::ENV_ID == 3) ? 2 : 0;
