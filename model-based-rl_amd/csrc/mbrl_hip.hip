@@ -119,7 +119,7 @@ struct WaveMap {
 #else
 #define MBRL_PLAN_SLOT(slot) (N - 1 - (slot))
 #endif
-constexpr int kKeyBits = 62;   // (3 bits x the last 10 mj_forward calls) of Lean::key, then the same of Lean::key2
+constexpr int kKeyBits = 62;   // Lean::key_value: per-mj_step solver passes of the whole rollout (+ line-search tie-break)
 constexpr int PLAN_NONE = 0, PLAN_WRITE = 1, PLAN_READ = 2, PLAN_RECORD = 3;   // RECORD: keys only (mbrl_step_record)
 constexpr unsigned ST_BADPLAN = MBRL_ST_BADPLAN;
 struct PlanHeader {
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(kBlock) MBRL_KERNEL_ATTR void rollout_kernel(int64_
     if (live) {
         Lean<M, double, LaneMem<double, kBlock>> S;
         S.status = 0;
-        S.key = 0; S.key2 = 0;
+        S.key_init(frame_skip * nsteps);
         S.mem.p = lds + t;
         const double *qp = qpos + unit * NV, *vp = qvel + unit * NV, *cp = ctrl + unit * NU;
         double d = eps;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(kBlock) MBRL_KERNEL_ATTR void rollout_kernel(int64_
             // buffer pointer advanced by its unit offset and needs to know nothing else about that plan)
             const PlanOffsets po(N, NS);
             reinterpret_cast<uint64_t *>(plan + po.key_in)[unit] =
-                (uint64_t(S.key & 0x3fffffffu) << 32) | uint64_t(S.key2 & 0x3fffffffu);
+                S.key_value(frame_skip * nsteps);
             if (plan_mode == PLAN_WRITE) reinterpret_cast<uint32_t *>(plan + po.idx_in)[unit] = uint32_t(unit);
         }
     } else {

@@ -320,7 +320,13 @@ struct Lean {
     uint32_t pair_on;
     unsigned status;
     int newton_iters;
-    uint32_t key, key2;      // see forward(); the caller zeroes them
+    // Control-flow signature of the rollout (the launch planner sorts the units by it, mbrl_fd_plan): per mj_step, oldest
+    // step in the most significant bits, the number of Hessian passes of its dynamics evaluation(s) -- in as many bits
+    // per step as let the WHOLE rollout fit 62 bits (key_init) -- and, for short rollouts, the line-search evaluations
+    // as a tie-break (key2).  Units with equal signatures take the same branches.
+    uint64_t key;
+    uint32_t key2;
+    int key_shift, key_left;             // bits per mj_step; steps still to record
     uint32_t ls_iters;
     MBRL_PHASE_MEMBER
 
@@ -1213,12 +1219,6 @@ struct Lean {
         newton_iters = 0;
         ls_iters = 0;
         if (constrained) solve_constraints();
-        // control-flow signature of the rollout: 3 bits per mj_forward (Hessian passes, 0 = unconstrained), latest in the
-        // low bits.  Units with equal signatures take the same branches; the launch planner sorts by it (mbrl_fd_plan).
-        key = (key << 3) | uint32_t(newton_iters < 7 ? newton_iters : 7);
-        // tie-break among equal pass patterns: line-search evaluations per mj_forward.  (Measured alternatives -- number of
-        // touching capsules, which capsules touch, limits on/off -- order the units no better: 6.59 .. 6.70 vs 6.62 ms.)
-        key2 = (key2 << 3) | (ls_iters < 7 ? ls_iters : 7u);
         MBRL_PIN(qacc, NV); MBRL_PIN(fcon, NV);
         MBRL_PHASE(6);
     }
@@ -1245,8 +1245,29 @@ struct Lean {
         }
     }
 
+    // `steps` = mj_steps of the whole rollout (frame_skip x env steps)
+    MBRL_HD void key_init(int steps) {
+        key = 0; key2 = 0;
+        key_shift = steps <= 20 ? 3 : (steps <= 31 ? 2 : 1);
+        key_left = 62 / key_shift;
+    }
+    // (Measured alternatives for the tie-break -- number of touching capsules, which capsules touch, limits on/off --
+    // order the units no better: 6.59 .. 6.70 vs 6.62 ms.)
+    MBRL_HD void key_note(uint32_t passes, uint32_t line_evals) {
+        if (key_left > 0) {
+            const uint32_t cap = (1u << key_shift) - 1u;
+            key = (key << key_shift) | uint64_t(passes < cap ? passes : cap);
+            key_left--;
+        }
+        key2 = (key2 << 3) | (line_evals < 7 ? line_evals : 7u);
+    }
+    // sort key: short rollouts (<= 10 mj_steps, 30 bits of passes) carry the line-search tie-break in the low word
+    MBRL_HD uint64_t key_value(int steps) const {
+        return steps <= 10 ? ((key & 0x3fffffffull) << 32) | uint64_t(key2 & 0x3fffffffu) : key;
+    }
+
     MBRL_HD void step() {
-        if (!M::RK4) { forward(); euler(); MBRL_PHASE(7); return; }
+        if (!M::RK4) { forward(); key_note(uint32_t(newton_iters), ls_iters); euler(); MBRL_PHASE(7); return; }
         // classic RK4; stage i uses only stage i-1 (tableau 1/2, 1/2, 1), weights 1/6 1/3 1/3 1/6.  ONE call site of
         // forward() for the four stages: inlined twice (first stage + loop) the Walker2d kernel was 97 KB of code,
         // beyond the 64 KB instruction cache.
@@ -1256,6 +1277,7 @@ struct Lean {
             q0[j] = mem.ld(LY::OQ + j); v0[j] = mem.ld(LY::OV + j);
             aq[j] = T(0.0); av[j] = T(0.0);
         }
+        uint32_t kpass = 0, kline = 0;       // this step's signature: most passes of a stage, line evaluations of all
         MBRL_NOUNROLL
         for (int i = 0; i < 4; i++) {
             if (i > 0) {
@@ -1268,10 +1290,13 @@ struct Lean {
                 }
             }
             forward();
+            kpass = uint32_t(newton_iters) > kpass ? uint32_t(newton_iters) : kpass;
+            kline += ls_iters;
             const double bi = (i == 0 || i == 3) ? 1.0 / 6 : 1.0 / 3;
             MBRL_UNROLL
             for (int j = 0; j < NV; j++) { aq[j] = aq[j] + bi * mem.ld(LY::OV + j); av[j] = av[j] + bi * qacc[j]; }
         }
+        key_note(kpass, kline);
         MBRL_UNROLL
         for (int j = 0; j < NV; j++) { mem.st(LY::OQ + j, q0[j] + M::DT * aq[j]); mem.st(LY::OV + j, v0[j] + M::DT * av[j]); }
     }

@@ -97,6 +97,7 @@ struct Host {
         for (int j = 0; j < M::NV; j++) { col[LY::OQ + j] = t_var<T>(q[j]); col[LY::OV + j] = t_var<T>(v[j]); }
         for (int u = 0; u < M::NU; u++) col[LY::OC + u] = t_var<T>(c[u]);
         S.status = 0;
+        S.key_init(1);
     }
 };
 
