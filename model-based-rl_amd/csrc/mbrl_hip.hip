@@ -119,7 +119,7 @@ struct WaveMap {
 #else
 #define MBRL_PLAN_SLOT(slot) (N - 1 - (slot))
 #endif
-constexpr int kKeyBits = 62;   // Lean::key_value: per-mj_step solver passes of the whole rollout (+ line-search tie-break)
+constexpr int kKeyBits = 62;   // Lean::key_value: solver passes per mj_step + line-search tie-break, or total / row union / passes
 constexpr int PLAN_NONE = 0, PLAN_WRITE = 1, PLAN_READ = 2, PLAN_RECORD = 3;   // RECORD: keys only (mbrl_step_record)
 constexpr unsigned ST_BADPLAN = MBRL_ST_BADPLAN;
 struct PlanHeader {

@@ -320,13 +320,16 @@ struct Lean {
     uint32_t pair_on;
     unsigned status;
     int newton_iters;
-    // Control-flow signature of the rollout (the launch planner sorts the units by it, mbrl_fd_plan): per mj_step, oldest
-    // step in the most significant bits, the number of Hessian passes of its dynamics evaluation(s) -- in as many bits
-    // per step as let the WHOLE rollout fit 62 bits (key_init) -- and, for short rollouts, the line-search evaluations
-    // as a tie-break (key2).  Units with equal signatures take the same branches.
+    // Control-flow signature of the rollout (the launch planner sorts the units by it, mbrl_fd_plan; units with equal
+    // signatures take the same branches).  Rollouts of up to 10 mj_steps: 3 bits of Hessian passes per step, oldest step
+    // most significant, then 3 bits per step of line-search evaluations as the tie-break (key2).  Longer rollouts
+    // (Hopper 20, Walker2d 25 steps): [passes of the whole rollout / 4 : 6 bits][rows that were EVER active (floor
+    // candidates, limits, pairs) : KEY_U bits][2 bits per step of passes, first KEY_REC steps] -- measured against a dozen
+    // other orders with tools/key_probe.py, profiles/r02_experiments.md.  key2 then carries the row union in bits 0..23
+    // and the pass total in bits 24..31.
     uint64_t key;
     uint32_t key2;
-    int key_shift, key_left;             // bits per mj_step; steps still to record
+    int key_left;                        // long rollouts: steps still to record; -1: short rollout
     uint32_t ls_iters;
     MBRL_PHASE_MEMBER
 
@@ -1245,29 +1248,42 @@ struct Lean {
         }
     }
 
+    static constexpr int key_first_lim() { int f = 0; while (f < NV - 1 && !M::limited[f]) f++; return f; }
+    static constexpr int key_last_lim() { int l = NV - 1; while (l > 0 && !M::limited[l]) l--; return l; }
+    static constexpr int KEY_LIM0 = key_first_lim(), KEY_NLIM = key_last_lim() - key_first_lim() + 1;
+    static constexpr int KEY_U = LY::NCAND + KEY_NLIM + M::NPAIR;      // bits of the row union
+    static constexpr int KEY_REC = (62 - 6 - KEY_U) / 2;               // steps whose passes fit behind it
+    static_assert(KEY_U <= 24 && KEY_REC >= 8, "row union must fit key2's low 24 bits");
     // `steps` = mj_steps of the whole rollout (frame_skip x env steps)
-    MBRL_HD void key_init(int steps) {
-        key = 0; key2 = 0;
-        key_shift = steps <= 20 ? 3 : (steps <= 31 ? 2 : 1);
-        key_left = 62 / key_shift;
+    MBRL_HD void key_init(int steps) { key = 0; key2 = 0; key_left = steps <= 10 ? -1 : KEY_REC; }
+    // rows active in the dynamics evaluation just made, packed for the union
+    MBRL_HD uint32_t key_rows() const {
+        return cand_on | ((lim_on >> KEY_LIM0) << LY::NCAND) | (pair_on << (LY::NCAND + KEY_NLIM));
     }
-    // (Measured alternatives for the tie-break -- number of touching capsules, which capsules touch, limits on/off --
-    // order the units no better: 6.59 .. 6.70 vs 6.62 ms.)
-    MBRL_HD void key_note(uint32_t passes, uint32_t line_evals) {
+    // one mj_step: its Hessian passes (RK4: most of a stage), line-search evaluations and active rows
+    MBRL_HD void key_note(uint32_t passes, uint32_t line_evals, uint32_t rows) {
+        const uint32_t p7 = passes < 7u ? passes : 7u;
+        if (key_left < 0) {
+            key = (key << 3) | uint64_t(p7);
+            key2 = (key2 << 3) | (line_evals < 7u ? line_evals : 7u);
+            return;
+        }
         if (key_left > 0) {
-            const uint32_t cap = (1u << key_shift) - 1u;
-            key = (key << key_shift) | uint64_t(passes < cap ? passes : cap);
+            key = (key << 2) | uint64_t(p7 < 2u ? 0u : (p7 > 4u ? 3u : p7 - 1u));   // 0-1, 2, 3, 4+ passes
             key_left--;
         }
-        key2 = (key2 << 3) | (line_evals < 7 ? line_evals : 7u);
+        uint32_t tot = (key2 >> 24) + p7;
+        tot = tot < 255u ? tot : 255u;
+        key2 = ((key2 | rows) & 0xffffffu) | (tot << 24);
     }
-    // sort key: short rollouts (<= 10 mj_steps, 30 bits of passes) carry the line-search tie-break in the low word
     MBRL_HD uint64_t key_value(int steps) const {
-        return steps <= 10 ? ((key & 0x3fffffffull) << 32) | uint64_t(key2 & 0x3fffffffu) : key;
+        if (steps <= 10) return ((key & 0x3fffffffull) << 32) | uint64_t(key2 & 0x3fffffffu);
+        const uint32_t tq = (key2 >> 26) < 63u ? (key2 >> 26) : 63u;           // pass total / 4
+        return (uint64_t(tq) << (KEY_U + 2 * KEY_REC)) | (uint64_t(key2 & ((1u << KEY_U) - 1u)) << (2 * KEY_REC)) | key;
     }
 
     MBRL_HD void step() {
-        if (!M::RK4) { forward(); key_note(uint32_t(newton_iters), ls_iters); euler(); MBRL_PHASE(7); return; }
+        if (!M::RK4) { forward(); key_note(uint32_t(newton_iters), ls_iters, key_rows()); euler(); MBRL_PHASE(7); return; }
         // classic RK4; stage i uses only stage i-1 (tableau 1/2, 1/2, 1), weights 1/6 1/3 1/3 1/6.  ONE call site of
         // forward() for the four stages: inlined twice (first stage + loop) the Walker2d kernel was 97 KB of code,
         // beyond the 64 KB instruction cache.
@@ -1277,7 +1293,7 @@ struct Lean {
             q0[j] = mem.ld(LY::OQ + j); v0[j] = mem.ld(LY::OV + j);
             aq[j] = T(0.0); av[j] = T(0.0);
         }
-        uint32_t kpass = 0, kline = 0;       // this step's signature: most passes of a stage, line evaluations of all
+        uint32_t kpass = 0, kline = 0, krows = 0;   // this step's signature: most passes of a stage, line evaluations and rows of all
         MBRL_NOUNROLL
         for (int i = 0; i < 4; i++) {
             if (i > 0) {
@@ -1292,11 +1308,12 @@ struct Lean {
             forward();
             kpass = uint32_t(newton_iters) > kpass ? uint32_t(newton_iters) : kpass;
             kline += ls_iters;
+            krows |= key_rows();
             const double bi = (i == 0 || i == 3) ? 1.0 / 6 : 1.0 / 3;
             MBRL_UNROLL
             for (int j = 0; j < NV; j++) { aq[j] = aq[j] + bi * mem.ld(LY::OV + j); av[j] = av[j] + bi * qacc[j]; }
         }
-        key_note(kpass, kline);
+        key_note(kpass, kline, krows);
         MBRL_UNROLL
         for (int j = 0; j < NV; j++) { mem.st(LY::OQ + j, q0[j] + M::DT * aq[j]); mem.st(LY::OV + j, v0[j] + M::DT * av[j]); }
     }

@@ -130,6 +130,24 @@ static void stepN(int frame_skip, int64_t N, const double *q, const double *v, c
     }
 }
 
+
+// per-mj_step control-flow trace of N nominal rollouts (tools/key_probe.py: what should the launch plan sort by?):
+// word = passes | line evaluations << 4 | floor candidates << 8 (14 bits) | limits of dofs 3.. << 22 (6 bits) | pairs << 28,
+// as the solver left them
+template <class M>
+static void traceN(int steps, int64_t N, const double *q, const double *v, const double *c, uint32_t *tr) {
+    for (int64_t i = 0; i < N; i++) {
+        Host<M, double> h;
+        h.load(q + i * M::NV, v + i * M::NV, c + i * M::NU);
+        for (int k = 0; k < steps; k++) {
+            h.S.step();
+            const uint32_t ps = uint32_t(h.S.newton_iters) < 15u ? uint32_t(h.S.newton_iters) : 15u;
+            const uint32_t ls = h.S.ls_iters < 15u ? h.S.ls_iters : 15u;
+            tr[i * steps + k] = ps | ls << 4 | (h.S.cand_on & 0x3fffu) << 8 | ((h.S.lim_on >> (M::NV > 3 ? 3 : 0)) & 0x3fu) << 22 | (h.S.pair_on & 7u) << 28;
+        }
+    }
+}
+
 #define DISPATCH(id, CALL)                                             \
     switch (id) {                                                      \
     case 0: { using M = MdlInvertedPendulum; CALL; } break;            \
@@ -139,6 +157,16 @@ static void stepN(int frame_skip, int64_t N, const double *q, const double *v, c
     case 4: { using M = MdlWalker2d; CALL; } break;                    \
     case 5: { using M = MdlHalfCheetah; CALL; } break;                 \
     default: return -1;                                                \
+    }
+#define DISPATCH_V(id, CALL)                                           \
+    switch (id) {                                                      \
+    case 0: { using M = MdlInvertedPendulum; CALL; } break;            \
+    case 1: { using M = MdlInvertedDoublePendulum; CALL; } break;      \
+    case 2: { using M = MdlSwimmer; CALL; } break;                     \
+    case 3: { using M = MdlHopper; CALL; } break;                      \
+    case 4: { using M = MdlWalker2d; CALL; } break;                    \
+    case 5: { using M = MdlHalfCheetah; CALL; } break;                 \
+    default: break;                                                    \
     }
 
 extern "C" {
@@ -192,6 +220,19 @@ int twin_solver_stats(int id, int64_t N, const double *q, const double *v, const
         (void)twin_forward(id, q + i * nv, v + i * nv, c + i * nu, qa, fs, fc, &it, &na);
         *passes += it; *constrained += it > 0 ? 1 : 0;
     }
+    return 0;
+}
+int twin_trace(int id, int steps, int64_t N, const double *q, const double *v, const double *c, uint32_t *tr, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    int nv = 0, nu = 0;
+    DISPATCH(id, (nv = M::NV, nu = M::NU));
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; t++)
+        th.emplace_back([&, t]() {
+            const int64_t lo = N * t / nthreads, hi = N * (t + 1) / nthreads;
+            DISPATCH_V(id, (traceN<M>(steps, hi - lo, q + lo * nv, v + lo * nv, c + lo * nu, tr + lo * steps)));
+        });
+    for (auto &x : th) x.join();
     return 0;
 }
 }
