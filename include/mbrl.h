@@ -28,7 +28,8 @@ extern "C" {
  * backward.py:371,374) */
 #define MBRL_ST_NONFINITE  1u  /* NaN/Inf state or non-positive pivot */
 #define MBRL_ST_NOCONVERGE 2u  /* constraint solver hit its iteration cap */
-#define MBRL_ST_OVERFLOW   4u  /* reserved (contact capacity) */
+#define MBRL_ST_OVERFLOW   4u  /* internal: more than 8 floor contacts at once.  Callers that pass `status` never see it:
+                                * the entry points re-run such units with full contact capacity */
 #define MBRL_ST_DEGENERATE 8u  /* reserved; not raised since ABI 6: crossing capsule axes have a defined normal */
 #define MBRL_ST_BADPLAN    16u /* mbrl_fd_jacobians_planned: the plan was made for another batch (N, nsteps, model) */
 

@@ -17,6 +17,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -142,75 +143,30 @@ struct PlanLayout {
     size_t sort_tmp, sort_bytes, total;
 };
 
-// STEP_NAME only gives plain-step launches their own symbol in profiler output (the body does not use it,
-// so both instantiations are compiled from identical IR; tests/test_gpu_parity.py checks the bits).
-#ifdef MBRL_WAVES_PER_EU
-#define MBRL_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(MBRL_WAVES_PER_EU)))
-#else
-#define MBRL_KERNEL_ATTR
-#endif
-template <class M, bool STEP_NAME>
-__global__ __launch_bounds__(kBlock) MBRL_KERNEL_ATTR void rollout_kernel(int64_t N, int frame_skip, int nsteps, double eps, int mode,
-                                                          const double *__restrict__ qpos,
-                                                          const double *__restrict__ qvel,
-                                                          const double *__restrict__ ctrl,
-                                                          const double *__restrict__ ctrl_pert, double *__restrict__ dsds,
-                                                          double *__restrict__ dsda, double *__restrict__ drds,
-                                                          double *__restrict__ drda, double *__restrict__ s_next,
-                                                          double *__restrict__ qpos_next, double *__restrict__ qvel_next,
-                                                          double *__restrict__ reward, uint32_t *__restrict__ status,
-                                                          char *__restrict__ plan, int plan_mode) {
-    using LY = Layout<M>;
-    constexpr int NV = M::NV, NU = M::NU, NS = 2 * NV, ROW = NS + 1, NP = NU + 2 * NV;
-    static_assert(kBlock == 64, "one wave per workgroup");
-    static_assert(1 + 2 * NP <= kBlock, "a unit's rollouts must fit one wave");
-    __shared__ double lds[LY::NMEM * kBlock];   // lane columns
-
+// The rollouts of one wave: lane t runs rollout p of `unit` (p = 0: nominal), differences against lane `nom` (or the
+// plan's nominal) and writes its Jacobian column.  Shared by the fast kernel (KCAP = 8 contact slots, FIX = false) and
+// the fix-up kernel (one slot per floor candidate, FIX = true); force-inlined, so the kernels stay single functions.
+template <class M, int KCAP, bool FIX>
+__device__ __forceinline__ void wave_rollouts(double *lds, const int t, const int64_t unit, const int p, const int nom,
+                                              const bool primary, const bool live, const bool planned, int64_t N,
+                                              int frame_skip, int nsteps, double eps, int mode,
+                                              const double *__restrict__ qpos, const double *__restrict__ qvel,
+                                              const double *__restrict__ ctrl, const double *__restrict__ ctrl_pert,
+                                              double *__restrict__ dsds, double *__restrict__ dsda,
+                                              double *__restrict__ drds, double *__restrict__ drda,
+                                              double *__restrict__ s_next, double *__restrict__ qpos_next,
+                                              double *__restrict__ qvel_next, double *__restrict__ reward,
+                                              uint32_t *__restrict__ status, char *__restrict__ plan, int plan_mode) {
+    using LY = Layout<M, KCAP>;
+    constexpr int NV = M::NV, NU = M::NU, NS = 2 * NV, ROW = NS + 1;
     const bool central = mode == MODE_CENTRAL;
-    const WaveMap wm(mode == MODE_STEP ? 1 : (central ? 1 + 2 * NP : 1 + NP), central);
-    const int t = threadIdx.x;
-    int u, p, nom;
-    bool primary, live;
-    int64_t unit;
-    const bool planned = plan_mode == PLAN_READ;
-    if (planned) {
-        const PlanHeader *hd = reinterpret_cast<const PlanHeader *>(plan);
-        if (hd->magic != kPlanMagic || hd->units != N || hd->nsteps != nsteps || hd->frame_skip != frame_skip ||
-            hd->env_id != M::ENV_ID) {
-            const int64_t g = int64_t(blockIdx.x) * kBlock + t;     // the first N lanes flag one unit each
-            if (status && g < N) atomicOr(&status[g], ST_BADPLAN);
-            return;
-        }
-    }
-    if (plan_mode == PLAN_WRITE && blockIdx.x == 0 && t == 0) {
-        PlanHeader *hd = reinterpret_cast<PlanHeader *>(plan);
-        hd->magic = kPlanMagic; hd->units = N; hd->nsteps = nsteps; hd->frame_skip = frame_skip; hd->env_id = M::ENV_ID;
-        hd->pad = 0;
-    }
-    if (planned) {
-        // planned launch (mbrl_fd_jacobians_planned): perturbed rollouts only, units in the planner's order, every
-        // lane busy; the nominal results come from the plan (nom_s, nom_r).  2 NP is even, so a central couple
-        // (+eps on the even lane, -eps on the next) never straddles two waves.
-        const int64_t g = int64_t(blockIdx.x) * kBlock + t;
-        const int64_t slot = central ? g / (2 * NP) : g / NP;
-        p = 1 + int(g - slot * (central ? 2 * NP : NP));
-        live = slot < N;
-        unit = live ? int64_t(reinterpret_cast<const uint32_t *>(plan + PlanOffsets(N, NS).perm)[MBRL_PLAN_SLOT(slot)]) : 0;
-        // a plan made for another batch holds arbitrary indices here: never follow one out of the arrays
-        if (unit >= N) { live = false; unit = 0; }
-        nom = 0; primary = true;
-    } else {
-        const bool mapped = wm.lane(int(blockIdx.x & 1u), t, u, p, nom, primary);
-        unit = int64_t(blockIdx.x >> 1) * wm.upp + u;
-        live = mapped && unit < N;
-    }
     MBRL_STAMP(0);
     double o[ROW];
     unsigned st = 0;
     int idx = -1;            // perturbed input (ctrl, qvel, qpos order), -1: nominal
     bool minus = false;      // the -eps member of a central couple
     if (live) {
-        Lean<M, double, LaneMem<double, kBlock>> S;
+        Lean<M, double, LaneMem<double, kBlock>, KCAP> S;
         S.status = 0;
         S.key_init(frame_skip * nsteps);
         S.mem.p = lds + t;
@@ -310,9 +266,121 @@ __global__ __launch_bounds__(kBlock) MBRL_KERNEL_ATTR void rollout_kernel(int64_
         }
         if (reward) reward[unit] = o[NS];
     }
-    // status: OR over the unit's rollouts; a unit can live in two waves, so it is accumulated in HBM (zeroed by the host)
-    if (status && live && st) atomicOr(&status[unit], st);
+    if (FIX) {
+        // the fix-up wave owns the whole unit: the OR over its rollouts REPLACES the word the fast launch left
+        unsigned all = 0;
+#pragma unroll
+        for (int b = 0; b < 5; b++)
+            if (__builtin_amdgcn_ballot_w64(live && ((st >> b) & 1u))) all |= 1u << b;
+        if (t == 0) status[unit] = all;
+    } else {
+        // status: OR over the unit's rollouts; a unit can live in two waves, so it is accumulated in HBM (zeroed by the host)
+        if (status && live && st) atomicOr(&status[unit], st);
+    }
     MBRL_STAMP(3);
+}
+
+// STEP_NAME only gives plain-step launches their own symbol in profiler output (the body does not use it,
+// so both instantiations are compiled from identical IR; tests/test_gpu_parity.py checks the bits).
+#ifdef MBRL_WAVES_PER_EU
+#define MBRL_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(MBRL_WAVES_PER_EU)))
+#else
+#define MBRL_KERNEL_ATTR
+#endif
+template <class M, bool STEP_NAME>
+__global__ __launch_bounds__(kBlock) MBRL_KERNEL_ATTR void rollout_kernel(int64_t N, int frame_skip, int nsteps, double eps, int mode,
+                                                          const double *__restrict__ qpos,
+                                                          const double *__restrict__ qvel,
+                                                          const double *__restrict__ ctrl,
+                                                          const double *__restrict__ ctrl_pert, double *__restrict__ dsds,
+                                                          double *__restrict__ dsda, double *__restrict__ drds,
+                                                          double *__restrict__ drda, double *__restrict__ s_next,
+                                                          double *__restrict__ qpos_next, double *__restrict__ qvel_next,
+                                                          double *__restrict__ reward, uint32_t *__restrict__ status,
+                                                          char *__restrict__ plan, int plan_mode) {
+    using LY = Layout<M>;
+    constexpr int NV = M::NV, NU = M::NU, NS = 2 * NV, ROW = NS + 1, NP = NU + 2 * NV;
+    static_assert(kBlock == 64, "one wave per workgroup");
+    static_assert(1 + 2 * NP <= kBlock, "a unit's rollouts must fit one wave");
+    __shared__ double lds[LY::NMEM * kBlock];   // lane columns
+
+    const bool central = mode == MODE_CENTRAL;
+    const WaveMap wm(mode == MODE_STEP ? 1 : (central ? 1 + 2 * NP : 1 + NP), central);
+    const int t = threadIdx.x;
+    int u, p, nom;
+    bool primary, live;
+    int64_t unit;
+    const bool planned = plan_mode == PLAN_READ;
+    if (planned) {
+        const PlanHeader *hd = reinterpret_cast<const PlanHeader *>(plan);
+        if (hd->magic != kPlanMagic || hd->units != N || hd->nsteps != nsteps || hd->frame_skip != frame_skip ||
+            hd->env_id != M::ENV_ID) {
+            const int64_t g = int64_t(blockIdx.x) * kBlock + t;     // the first N lanes flag one unit each
+            if (status && g < N) atomicOr(&status[g], ST_BADPLAN);
+            return;
+        }
+    }
+    if (plan_mode == PLAN_WRITE && blockIdx.x == 0 && t == 0) {
+        PlanHeader *hd = reinterpret_cast<PlanHeader *>(plan);
+        hd->magic = kPlanMagic; hd->units = N; hd->nsteps = nsteps; hd->frame_skip = frame_skip; hd->env_id = M::ENV_ID;
+        hd->pad = 0;
+    }
+    if (planned) {
+        // planned launch (mbrl_fd_jacobians_planned): perturbed rollouts only, units in the planner's order, every
+        // lane busy; the nominal results come from the plan (nom_s, nom_r).  2 NP is even, so a central couple
+        // (+eps on the even lane, -eps on the next) never straddles two waves.
+        const int64_t g = int64_t(blockIdx.x) * kBlock + t;
+        const int64_t slot = central ? g / (2 * NP) : g / NP;
+        p = 1 + int(g - slot * (central ? 2 * NP : NP));
+        live = slot < N;
+        unit = live ? int64_t(reinterpret_cast<const uint32_t *>(plan + PlanOffsets(N, NS).perm)[MBRL_PLAN_SLOT(slot)]) : 0;
+        // a plan made for another batch holds arbitrary indices here: never follow one out of the arrays
+        if (unit >= N) { live = false; unit = 0; }
+        nom = 0; primary = true;
+    } else {
+        const bool mapped = wm.lane(int(blockIdx.x & 1u), t, u, p, nom, primary);
+        unit = int64_t(blockIdx.x >> 1) * wm.upp + u;
+        live = mapped && unit < N;
+    }
+    wave_rollouts<M, 8, false>(lds, t, unit, p, nom, primary, live, planned, N, frame_skip, nsteps, eps, mode, qpos, qvel, ctrl,
+                               ctrl_pert, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward, status, plan, plan_mode);
+}
+
+// Fix-up of the units the fast kernel flagged MBRL_ST_OVERFLOW (more than 8 capsule ends on the floor at once: a walker
+// lying flat).  Same rollouts with one contact slot per floor candidate (a larger LDS column: two waves per CU instead of
+// four -- irrelevant for the handful of units concerned).  Each wave scans a slice of the status words and, for every
+// flagged unit it finds, runs ALL of that unit's rollouts itself (R <= 64 lanes, nominal in lane 0) and overwrites the
+// unit's outputs, plan entries and status word.  Launched after every rollout launch of a model with more than 8 floor
+// candidates; with nothing flagged it reads N status words and exits.
+template <class M>
+__global__ __launch_bounds__(kBlock) void overflow_kernel(int64_t N, int frame_skip, int nsteps, double eps, int mode,
+                                                           const double *__restrict__ qpos,
+                                                           const double *__restrict__ qvel,
+                                                           const double *__restrict__ ctrl,
+                                                           const double *__restrict__ ctrl_pert, double *__restrict__ dsds,
+                                                           double *__restrict__ dsda, double *__restrict__ drds,
+                                                           double *__restrict__ drda, double *__restrict__ s_next,
+                                                           double *__restrict__ qpos_next, double *__restrict__ qvel_next,
+                                                           double *__restrict__ reward, uint32_t *__restrict__ status,
+                                                           char *__restrict__ plan, int plan_mode) {
+    constexpr int KALL = 32;                       // Layout clamps it to the number of floor candidates
+    using LY = Layout<M, KALL>;
+    constexpr int NP = M::NU + 2 * M::NV;
+    static_assert(LY::NMEM * kBlock * sizeof(double) <= 65536, "the wide column must fit one workgroup's LDS");
+    __shared__ double lds[LY::NMEM * kBlock];
+    const int R = mode == MODE_STEP ? 1 : (mode == MODE_CENTRAL ? 1 + 2 * NP : 1 + NP);
+    const int t = threadIdx.x;
+    for (int64_t base = int64_t(blockIdx.x) * kBlock; base < N; base += int64_t(gridDim.x) * kBlock) {
+        const unsigned s = base + t < N ? status[base + t] : 0u;
+        unsigned long long pend = __builtin_amdgcn_ballot_w64((s & ST_OVERFLOW) != 0u);
+        while (pend) {                             // wave-uniform: every lane sees the same ballot
+            const int l = __builtin_ctzll(pend);
+            pend &= pend - 1;
+            wave_rollouts<M, KALL, true>(lds, t, base + l, t, 0, true, t < R, false, N, frame_skip, nsteps, eps, mode, qpos, qvel,
+                                         ctrl, ctrl_pert, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward, status,
+                                         plan, plan_mode);
+        }
+    }
 }
 
 // mbrl_fd_plan_finish: header and identity order of a plan whose keys and nominal results were recorded by step launches.
@@ -469,6 +537,19 @@ static int launch_rollouts(const mbrl_model *m, int64_t N, int mode, const doubl
         hipLaunchKernelGGL((rollout_kernel<M, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, N, m->frame_skip, nsteps,
                            eps, mode, qpos, qvel, ctrl, ctrl_pert, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward,
                            status, plan, plan_mode);
+    // Models with more floor candidates than the fast kernel has contact slots: re-run whatever it flagged
+    // MBRL_ST_OVERFLOW with one slot per candidate (overflow_kernel).  A planned launch's flagged units are redone whole,
+    // nominal included, so the fix-up needs no plan; plan and record launches re-record their units' plan entries.
+    // (MBRL_NO_OVERFLOW_FIXUP in the environment skips it: tests use that to see the flags the fast kernel raises.)
+    if constexpr ((Layout<M>::NCAND > Layout<M>::K)) {
+        if (status && !getenv("MBRL_NO_OVERFLOW_FIXUP")) {
+            int64_t fb = (N + kBlock - 1) / kBlock;
+            if (fb > 1024) fb = 1024;
+            hipLaunchKernelGGL((overflow_kernel<M>), dim3((unsigned)fb), dim3(kBlock), 0, st, N, m->frame_skip, nsteps, eps, mode,
+                               qpos, qvel, ctrl, ctrl_pert, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward, status,
+                               planned ? nullptr : plan, planned ? PLAN_NONE : plan_mode);
+        }
+    }
     return 0;
 }
 

@@ -283,25 +283,30 @@ struct Topo {
     static constexpr Tables T = make();
 };
 
-// layout of the per-lane memory column
-template <class M>
+// layout of the per-lane memory column; KCAP = most floor contacts held at once (the fast kernels keep 8 slots, the
+// fix-up kernel of mbrl_hip.hip one per candidate)
+template <class M, int KCAP = 8>
 struct Layout {
     using TP = Topo<M>;
     static constexpr int NV = M::NV, NU = M::NU;
     static constexpr int NLIM = TP::T.nlim, NCAND = TP::T.ncand;
-    static constexpr int K = NCAND < 8 ? NCAND : 8;            // contact slots (active rows beyond K: ST_OVERFLOW)
+    static constexpr int K = NCAND < KCAP ? NCAND : KCAP;      // contact slots (active rows beyond K: ST_OVERFLOW)
     // contact slots first: their (lane-dependent) addresses are then  base + slot * stride + small immediate
     static constexpr int OS = 0, OP = 5 * K, OL = OP + 5 * M::NPAIR, OQ = OL + 2 * NLIM, OV = OQ + NV, OC = OV + NV;
     static constexpr int NMEM = OC + NU;
 };
 
-template <class M, class T, class Mem>
+template <bool WIDE> struct RowMask { using type = uint32_t; };
+template <> struct RowMask<true> { using type = uint64_t; };
+
+template <class M, class T, class Mem, int KCAP = 8>
 struct Lean {
     static constexpr int NB = M::NB, NV = M::NV, NU = M::NU;
     using TP = Topo<M>;
-    using LY = Layout<M>;
+    using LY = Layout<M, KCAP>;
     static constexpr int K = LY::K;
-    static_assert(3 * K <= 32 && NV + M::NPAIR <= 32 && LY::NCAND <= 32, "row masks are 32-bit");
+    using CM = typename RowMask<(3 * K > 32)>::type;      // contact-row mask: 3 bits per slot
+    static_assert(3 * K <= 64 && NV + M::NPAIR <= 32 && LY::NCAND <= 32, "row masks are 32-bit (contacts: up to 64)");
 
     Mem mem;
     // ---- position-dependent, alive through a dynamics evaluation ----
@@ -815,7 +820,7 @@ struct Lean {
     // parent, so no per-body arrays of augmentations or forces exist.
     // WITH_H = false: forces and masks only (the closing evaluation of a converged solve).
     template <bool WITH_H>
-    MBRL_HD void newton_pass(const T *x, T (*H)[NV], T *jtf, uint32_t &lm, uint32_t &cm) const {
+    MBRL_HD void newton_pass(const T *x, T (*H)[NV], T *jtf, uint32_t &lm, CM &cm) const {
         lm = 0; cm = 0;
         Sp<T> Fp[NB];          // pair-row forces per body (models with capsule/capsule pairs only)
         if (M::NPAIR > 0) {
@@ -890,7 +895,7 @@ struct Lean {
                                 dnt = mu * (d0 - d1);
                                 dtt = (mu * mu) * (d0 + d1);
                             }
-                            cm |= rows << sh;
+                            cm |= CM(rows) << sh;
                             // n-direction (Pa, 0, 1), t-direction (-Pb, 1, 0)
                             Fc.w = Fc.w + (fn * Pa - ft * Pb); Fc.a = Fc.a + ft; Fc.b = Fc.b + fn;
                             if (WITH_H) {
@@ -967,7 +972,7 @@ struct Lean {
     }
 
     // derivative g and curvature h of the constraint cost along the search direction at step alpha
-    MBRL_HD void line_pass(const T *x, const T *sx, T alpha, T &g, T &h, uint32_t &lm, uint32_t &cm) const {
+    MBRL_HD void line_pass(const T *x, const T *sx, T alpha, T &g, T &h, uint32_t &lm, CM &cm) const {
         lm = 0; cm = 0;
         Pop<LY::OS, 5> cs;
         Pop<LY::OL, 2> ls;
@@ -1021,7 +1026,7 @@ struct Lean {
                     if (M::c_dim[gi] == 1) {
                         const T r = rn + alpha * sn;
                         const bool on = t_val(r) < 0.0;
-                        cm |= (on ? 4u : 0u) << sh;
+                        cm |= CM(on ? 4u : 0u) << sh;
                         const T d = on ? D : T(0.0);
                         g = g + (d * r) * sn; h = h + (d * sn) * sn;
                     } else {
@@ -1029,7 +1034,7 @@ struct Lean {
                         const T j0 = sn + mu * st, j1 = sn - mu * st;
                         const T r0 = (rn + mu * rt) + alpha * j0, r1 = (rn - mu * rt) + alpha * j1, r2 = rn + alpha * sn;
                         const bool on0 = t_val(r0) < 0.0, on1 = t_val(r1) < 0.0, on2 = t_val(r2) < 0.0;
-                        cm |= ((on0 ? 1u : 0u) | (on1 ? 2u : 0u) | (on2 ? 4u : 0u)) << sh;
+                        cm |= CM((on0 ? 1u : 0u) | (on1 ? 2u : 0u) | (on2 ? 4u : 0u)) << sh;
                         const T d0 = on0 ? D : T(0.0), d1 = on1 ? D : T(0.0), d2 = on2 ? T(2.0) * D : T(0.0);
                         g = g + (((d0 * r0) * j0 + (d1 * r1) * j1) + (d2 * r2) * sn);
                         h = h + (((d0 * j0) * j0 + (d1 * j1) * j1) + (d2 * sn) * sn);
@@ -1084,7 +1089,8 @@ struct Lean {
     // iteration (0 at the start, += alpha (M + arm) s per step) instead of being re-evaluated.
     MBRL_HD void solve_constraints() {
         newton_iters = 0;
-        uint32_t plm = ~0u, pcm = ~0u;
+        uint32_t plm = ~0u;
+        CM pcm = ~CM(0);
         bool converged = false;
         T gs[NV];
         MBRL_UNROLL
@@ -1093,7 +1099,8 @@ struct Lean {
             MBRL_LOOP_FENCE;
             MBRL_OPAQUE(cand_on); MBRL_OPAQUE(lim_on);   // keep the per-row bit tests inside the loop
             T H[NV][NV], jtf[NV], sx[NV];
-            uint32_t lm, cm;
+            uint32_t lm;
+            CM cm;
             MBRL_PHASE(8);
             newton_iters = it + 1;
             newton_pass<true>(qacc, H, jtf, lm, cm);
@@ -1143,14 +1150,16 @@ struct Lean {
                 return false;
             }
             T alpha = T(1.0), lo = T(0.0), hi = T(-1.0);  // hi < 0: no upper bracket yet
-            uint32_t llm = lm, lcm = cm;                   // active set the current alpha was derived from
+            uint32_t llm = lm;                             // active set the current alpha was derived from
+            CM lcm = cm;
             bool exact = false;
             MBRL_NOUNROLL
             for (int ls = 0; ls < kMaxLineSearch; ls++) {
                 MBRL_LOOP_FENCE;
                 MBRL_OPAQUE(cand_on); MBRL_OPAQUE(lim_on);
                 T g = a1 + alpha * a2, h = a2;
-                uint32_t nlm, ncm;
+                uint32_t nlm;
+                CM ncm;
                 ls_iters++;
                 line_pass(qacc, sx, alpha, g, h, nlm, ncm);
                 if (nlm == llm && ncm == lcm) { exact = true; break; }   // alpha is the exact root of its own piece

@@ -27,8 +27,7 @@ def test_hostile_states_step_matches_oracle(env):
     qo, vo, ro, so = o.step(q, v, c, nthreads=8)
     qn, vn, r, st = e.step(q, v, c)
     st = st.cpu().numpy()
-    overflow = 4                                  # contact capacity: the kernel keeps 8 floor contacts, the oracle 24
-    same = (st & ~overflow) == (so.astype(np.int32) & ~overflow)
+    same = st == so.astype(np.int32)              # incl. contact capacity: units beyond the fast kernel's 8 slots are re-run
     assert same.all(), (env, int((~same).sum()))
     ok = (so == 0) & (st == 0)
     assert ok.mean() > 0.5, ok.mean()
@@ -59,6 +58,6 @@ def test_hostile_states_linearise_without_fault(env):
         assert torch.equal(a[k], b[k]), k
     ref = o.fd_jacobians(q[:300], v[:300], c[:300], nthreads=8)
     st = a["status"].cpu().numpy()
-    assert ((st[:300] & ~4) == (ref["status"].astype(np.int32) & ~4)).all()
+    assert (st[:300] == ref["status"].astype(np.int32)).all()
     clean = a["status"] == 0
     assert bool(torch.isfinite(a["dsds"][clean]).all()) and bool(torch.isfinite(a["dsda"][clean]).all())

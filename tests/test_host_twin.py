@@ -54,7 +54,8 @@ def test_twin_step_matches_oracle(env, twin):
 
 @pytest.mark.parametrize("env", ("HopperEnv", "Walker2dEnv", "HalfCheetahEnv"))
 def test_contact_slots_suffice_on_trajectory_states(env, twin):
-    """The kernel keeps ACTIVE floor contacts in K = 8 compacted slots; more would raise ST_OVERFLOW."""
+    """The fast kernel keeps ACTIVE floor contacts in K = 8 compacted slots; units with more take the fix-up launch
+    (tests/test_gpu_overflow.py), which these on-trajectory samples never need."""
     o = Oracle(env)
     q, v, c = util.on_trajectory(o, env, 2000, seed=6, max_steps=40)
     i = util.ENVS.index(env)
