@@ -145,9 +145,10 @@ struct PlanLayout {
 
 // The rollouts of one wave: lane t runs rollout p of `unit` (p = 0: nominal), differences against lane `nom` (or the
 // plan's nominal) and writes its Jacobian column.  Shared by the fast kernel (KCAP = 8 contact slots, FIX = false) and
-// the fix-up kernel (one slot per floor candidate, FIX = true); force-inlined, so the kernels stay single functions.
-template <class M, int KCAP, bool FIX>
-__device__ __forceinline__ void wave_rollouts(double *lds, const int t, const int64_t unit, const int p, const int nom,
+// the fix-up kernel (one slot per floor candidate, FIX = true: returns the OR of the lanes' status words instead of
+// accumulating it in HBM); force-inlined, so the kernels stay single functions.  LSTRIDE = lanes per LDS column.
+template <class M, int KCAP, bool FIX, int LSTRIDE>
+__device__ __forceinline__ unsigned wave_rollouts(double *lds, const int t, const int64_t unit, const int p, const int nom,
                                               const bool primary, const bool live, const bool planned, int64_t N,
                                               int frame_skip, int nsteps, double eps, int mode,
                                               const double *__restrict__ qpos, const double *__restrict__ qvel,
@@ -166,7 +167,7 @@ __device__ __forceinline__ void wave_rollouts(double *lds, const int t, const in
     int idx = -1;            // perturbed input (ctrl, qvel, qpos order), -1: nominal
     bool minus = false;      // the -eps member of a central couple
     if (live) {
-        Lean<M, double, LaneMem<double, kBlock>, KCAP> S;
+        Lean<M, double, LaneMem<double, LSTRIDE>, KCAP> S;
         S.status = 0;
         S.key_init(frame_skip * nsteps);
         S.mem.p = lds + t;
@@ -266,18 +267,18 @@ __device__ __forceinline__ void wave_rollouts(double *lds, const int t, const in
         }
         if (reward) reward[unit] = o[NS];
     }
+    unsigned all = 0;
     if (FIX) {
-        // the fix-up wave owns the whole unit: the OR over its rollouts REPLACES the word the fast launch left
-        unsigned all = 0;
+        // the fix-up wave owns the whole unit: it REPLACES the word the fast launch left (overflow_kernel stores it)
 #pragma unroll
         for (int b = 0; b < 5; b++)
             if (__builtin_amdgcn_ballot_w64(live && ((st >> b) & 1u))) all |= 1u << b;
-        if (t == 0) status[unit] = all;
     } else {
         // status: OR over the unit's rollouts; a unit can live in two waves, so it is accumulated in HBM (zeroed by the host)
         if (status && live && st) atomicOr(&status[unit], st);
     }
     MBRL_STAMP(3);
+    return all;
 }
 
 // STEP_NAME only gives plain-step launches their own symbol in profiler output (the body does not use it,
@@ -342,16 +343,20 @@ __global__ __launch_bounds__(kBlock) MBRL_KERNEL_ATTR void rollout_kernel(int64_
         unit = int64_t(blockIdx.x >> 1) * wm.upp + u;
         live = mapped && unit < N;
     }
-    wave_rollouts<M, 8, false>(lds, t, unit, p, nom, primary, live, planned, N, frame_skip, nsteps, eps, mode, qpos, qvel, ctrl,
+    wave_rollouts<M, 8, false, kBlock>(lds, t, unit, p, nom, primary, live, planned, N, frame_skip, nsteps, eps, mode, qpos, qvel, ctrl,
                                ctrl_pert, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward, status, plan, plan_mode);
 }
 
 // Fix-up of the units the fast kernel flagged MBRL_ST_OVERFLOW (more than 8 capsule ends on the floor at once: a walker
-// lying flat).  Same rollouts with one contact slot per floor candidate (a larger LDS column: two waves per CU instead of
-// four -- irrelevant for the handful of units concerned).  Each wave scans a slice of the status words and, for every
-// flagged unit it finds, runs ALL of that unit's rollouts itself (R <= 64 lanes, nominal in lane 0) and overwrites the
-// unit's outputs, plan entries and status word.  Launched after every rollout launch of a model with more than 8 floor
-// candidates; with nothing flagged it reads N status words and exits.
+// lying flat).  Same rollouts with one contact slot per floor candidate.  Each wave scans a slice of the status words
+// and, for every flagged unit it finds, runs ALL of that unit's rollouts itself and overwrites the unit's outputs, plan
+// entries and status word.  Launched after every rollout launch of a model with more than 8 floor candidates; with
+// nothing flagged it reads N status words and exits.
+// The wider column must not make the workgroup harder to place than a fast-kernel wave: a launch on a second stream
+// competes with those for the slots they free (measured with 59 KB per workgroup: the dispatcher held CUs half empty
+// until two waves had drained, and the pipelined bench lost 2 %).  So the column is strided for 32 lanes, not 64 --
+// under the fast kernel's 38 912 B -- and a unit's rollouts run in chunks of at most 31 lanes: the nominal in lane 0
+// every time, perturbed rollouts (whole +-eps couples in central mode) in the lanes after it.
 template <class M>
 __global__ __launch_bounds__(kBlock) void overflow_kernel(int64_t N, int frame_skip, int nsteps, double eps, int mode,
                                                            const double *__restrict__ qpos,
@@ -364,11 +369,15 @@ __global__ __launch_bounds__(kBlock) void overflow_kernel(int64_t N, int frame_s
                                                            double *__restrict__ reward, uint32_t *__restrict__ status,
                                                            char *__restrict__ plan, int plan_mode) {
     constexpr int KALL = 32;                       // Layout clamps it to the number of floor candidates
+    constexpr int LANES = 32;
     using LY = Layout<M, KALL>;
     constexpr int NP = M::NU + 2 * M::NV;
-    static_assert(LY::NMEM * kBlock * sizeof(double) <= 65536, "the wide column must fit one workgroup's LDS");
-    __shared__ double lds[LY::NMEM * kBlock];
-    const int R = mode == MODE_STEP ? 1 : (mode == MODE_CENTRAL ? 1 + 2 * NP : 1 + NP);
+    static_assert(LY::NMEM * LANES * sizeof(double) <= Layout<M>::NMEM * kBlock * sizeof(double),
+                  "the fix-up workgroup must fit wherever a fast-kernel wave fits");
+    __shared__ double lds[LY::NMEM * LANES];
+    const bool central = mode == MODE_CENTRAL;
+    const int P = mode == MODE_STEP ? 0 : (central ? 2 * NP : NP);      // perturbed rollouts per unit
+    const int cap = central ? LANES - 2 : LANES - 1;                    // ... per chunk (couples stay whole)
     const int t = threadIdx.x;
     for (int64_t base = int64_t(blockIdx.x) * kBlock; base < N; base += int64_t(gridDim.x) * kBlock) {
         const unsigned s = base + t < N ? status[base + t] : 0u;
@@ -376,9 +385,16 @@ __global__ __launch_bounds__(kBlock) void overflow_kernel(int64_t N, int frame_s
         while (pend) {                             // wave-uniform: every lane sees the same ballot
             const int l = __builtin_ctzll(pend);
             pend &= pend - 1;
-            wave_rollouts<M, KALL, true>(lds, t, base + l, t, 0, true, t < R, false, N, frame_skip, nsteps, eps, mode, qpos, qvel,
-                                         ctrl, ctrl_pert, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward, status,
-                                         plan, plan_mode);
+            unsigned all = 0;
+            int off = 0;
+            do {
+                const int cnt = P - off < cap ? P - off : cap;
+                all |= wave_rollouts<M, KALL, true, LANES>(lds, t, base + l, t == 0 ? 0 : off + t, 0, true, t <= cnt, false, N,
+                                                           frame_skip, nsteps, eps, mode, qpos, qvel, ctrl, ctrl_pert, dsds, dsda,
+                                                           drds, drda, s_next, qpos_next, qvel_next, reward, status, plan, plan_mode);
+                off += cnt;
+            } while (off < P);
+            if (t == 0) status[base + l] = all;
         }
     }
 }

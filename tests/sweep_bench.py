@@ -78,7 +78,7 @@ def main():
     cpu = ["", "| env | CPU oracle 1 thread (Jacobians/s) | 16 threads | GPU / 1 thread |", "|---|---|---|---|"]
     for eid, env in enumerate(util.ENVS):
         eng = FdEngine(env)
-        N = 16384 if env == "Walker2dEnv" else 65536
+        N = 65536
         q, v, c = workloads.s2(eng, N, seed=0)
         nsample = 256 if env == "Walker2dEnv" else 2048
         qh, vh, ch = (x[:nsample].cpu().numpy().copy() for x in (q, v, c))
