@@ -143,91 +143,72 @@ struct PlanLayout {
     size_t sort_tmp, sort_bytes, total;
 };
 
-// The rollouts of one wave: lane t runs rollout p of `unit` (p = 0: nominal), differences against lane `nom` (or the
-// plan's nominal) and writes its Jacobian column.  Shared by the fast kernel (KCAP = 8 contact slots, FIX = false) and
-// the fix-up kernel (one slot per floor candidate, FIX = true: returns the OR of the lanes' status words instead of
-// accumulating it in HBM); force-inlined, so the kernels stay single functions.  LSTRIDE = lanes per LDS column.
-template <class M, int KCAP, bool FIX, int LSTRIDE>
-__device__ __forceinline__ unsigned wave_rollouts(double *lds, const int t, const int64_t unit, const int p, const int nom,
-                                              const bool primary, const bool live, const bool planned, int64_t N,
-                                              int frame_skip, int nsteps, double eps, int mode,
-                                              const double *__restrict__ qpos, const double *__restrict__ qvel,
-                                              const double *__restrict__ ctrl, const double *__restrict__ ctrl_pert,
-                                              double *__restrict__ dsds, double *__restrict__ dsda,
-                                              double *__restrict__ drds, double *__restrict__ drda,
-                                              double *__restrict__ s_next, double *__restrict__ qpos_next,
-                                              double *__restrict__ qvel_next, double *__restrict__ reward,
-                                              uint32_t *__restrict__ status, char *__restrict__ plan, int plan_mode) {
+// One lane's rollout: nsteps env steps from (qpos, qvel, ctrl)[unit] with input `idx` perturbed by d (idx < 0: nominal).
+// -> o = (s', r), the status bits and the control-flow key.  KCAP = contact slots, LSTRIDE = lanes per LDS column
+// (`col` = this lane's column).  Force-inlined: the kernels stay single functions.
+template <class M, int KCAP, int LSTRIDE>
+__device__ __forceinline__ void lane_rollout(double *col, const int64_t unit, const int idx, const double d, const bool central,
+                                             const bool minus, int frame_skip, int nsteps, const double *__restrict__ qpos,
+                                             const double *__restrict__ qvel, const double *__restrict__ ctrl,
+                                             const double *__restrict__ ctrl_pert, double *o, unsigned &st, uint64_t &key) {
     using LY = Layout<M, KCAP>;
-    constexpr int NV = M::NV, NU = M::NU, NS = 2 * NV, ROW = NS + 1;
-    const bool central = mode == MODE_CENTRAL;
-    MBRL_STAMP(0);
-    double o[ROW];
-    unsigned st = 0;
-    int idx = -1;            // perturbed input (ctrl, qvel, qpos order), -1: nominal
-    bool minus = false;      // the -eps member of a central couple
-    if (live) {
-        Lean<M, double, LaneMem<double, LSTRIDE>, KCAP> S;
-        S.status = 0;
-        S.key_init(frame_skip * nsteps);
-        S.mem.p = lds + t;
-        const double *qp = qpos + unit * NV, *vp = qvel + unit * NV, *cp = ctrl + unit * NU;
-        double d = eps;
-        if (p > 0) {
-            idx = p - 1;
-            if (central) { minus = idx & 1; d = minus ? -eps : eps; idx >>= 1; }
-        }
-        // closed-loop linearisation (backward.py:418-419,460-461): a state-perturbed rollout runs under the
-        // policy's action AT the perturbed state, row (unit, column[, sign]) of ctrl_pert; columns in qvel, qpos order
-        if (ctrl_pert && idx >= NU) {
-            const int64_t col = unit * (2 * NV) + (idx - NU);
-            cp = ctrl_pert + (central ? 2 * col + (minus ? 1 : 0) : col) * NU;
-        }
-#pragma unroll
-        for (int k = 0; k < NU; k++) S.mem.st(LY::OC + k, idx == k ? cp[k] + d : cp[k]);
-#pragma unroll
-        for (int j = 0; j < NV; j++) S.mem.st(LY::OV + j, idx == NU + j ? vp[j] + d : vp[j]);
-#pragma unroll
-        for (int j = 0; j < NV; j++) S.mem.st(LY::OQ + j, idx == NU + NV + j ? qp[j] + d : qp[j]);
-        double r = 0.0;
-#ifdef MBRL_PHASE_TIMING
-        {
-            unsigned long long &mbrl_phase_last = S.mbrl_phase_last;
-            for (int k = 0; k < 16; k++) s_phase_acc[threadIdx.x >> 6][k] = 0;
-            MBRL_PHASE(15);
-            MBRL_PHASE(10);
-        }
-#endif
-        for (int k = 0; k < nsteps; k++) r = S.env_step(frame_skip);
-#ifdef MBRL_PHASE_TIMING
-        {
-            unsigned long long &mbrl_phase_last = S.mbrl_phase_last;
-            MBRL_PHASE(9);
-            MBRL_PHASE(10);
-            if ((threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
-                for (int k = 0; k < 16; k++) atomicAdd(&g_phase_acc[k], s_phase_acc[threadIdx.x >> 6][k]);
-        }
-#endif
-        S.check_finite();
-#pragma unroll
-        for (int j = 0; j < NV; j++) { o[j] = S.mem.ld(LY::OQ + j); o[NV + j] = S.mem.ld(LY::OV + j); }
-        o[NS] = r;
-        st = S.status;
-        if (plan_mode == PLAN_WRITE || plan_mode == PLAN_RECORD) {
-            // (the key segment starts at a fixed offset, so a step launch that records into a larger plan gets the
-            // buffer pointer advanced by its unit offset and needs to know nothing else about that plan)
-            const PlanOffsets po(N, NS);
-            reinterpret_cast<uint64_t *>(plan + po.key_in)[unit] =
-                S.key_value(frame_skip * nsteps);
-            if (plan_mode == PLAN_WRITE) reinterpret_cast<uint32_t *>(plan + po.idx_in)[unit] = uint32_t(unit);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < ROW; j++) o[j] = 0.0;
+    constexpr int NV = M::NV, NU = M::NU, NS = 2 * NV;
+    Lean<M, double, LaneMem<double, LSTRIDE>, KCAP> S;
+    S.status = 0;
+    S.key_init(frame_skip * nsteps);
+    S.mem.p = col;
+    const double *qp = qpos + unit * NV, *vp = qvel + unit * NV, *cp = ctrl + unit * NU;
+    // closed-loop linearisation (backward.py:418-419,460-461): a state-perturbed rollout runs under the
+    // policy's action AT the perturbed state, row (unit, column[, sign]) of ctrl_pert; columns in qvel, qpos order
+    if (ctrl_pert && idx >= NU) {
+        const int64_t c = unit * (2 * NV) + (idx - NU);
+        cp = ctrl_pert + (central ? 2 * c + (minus ? 1 : 0) : c) * NU;
     }
-    MBRL_STAMP(1);
-    MBRL_STAMP(2);
+#pragma unroll
+    for (int k = 0; k < NU; k++) S.mem.st(LY::OC + k, idx == k ? cp[k] + d : cp[k]);
+#pragma unroll
+    for (int j = 0; j < NV; j++) S.mem.st(LY::OV + j, idx == NU + j ? vp[j] + d : vp[j]);
+#pragma unroll
+    for (int j = 0; j < NV; j++) S.mem.st(LY::OQ + j, idx == NU + NV + j ? qp[j] + d : qp[j]);
+    double r = 0.0;
+#ifdef MBRL_PHASE_TIMING
+    {
+        unsigned long long &mbrl_phase_last = S.mbrl_phase_last;
+        for (int k = 0; k < 16; k++) s_phase_acc[threadIdx.x >> 6][k] = 0;
+        MBRL_PHASE(15);
+        MBRL_PHASE(10);
+    }
+#endif
+    for (int k = 0; k < nsteps; k++) r = S.env_step(frame_skip);
+#ifdef MBRL_PHASE_TIMING
+    {
+        unsigned long long &mbrl_phase_last = S.mbrl_phase_last;
+        MBRL_PHASE(9);
+        MBRL_PHASE(10);
+        if ((threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
+            for (int k = 0; k < 16; k++) atomicAdd(&g_phase_acc[k], s_phase_acc[threadIdx.x >> 6][k]);
+    }
+#endif
+    S.check_finite();
+#pragma unroll
+    for (int j = 0; j < NV; j++) { o[j] = S.mem.ld(LY::OQ + j); o[NV + j] = S.mem.ld(LY::OV + j); }
+    o[NS] = r;
+    st = S.status;
+    key = S.key_value(frame_skip * nsteps);
+}
 
+// What a wave does with its lanes' results: every perturbed lane differences its own (s', r) against the reference lane
+// of its unit in THIS wave (forward: the nominal, lane `nom`, or the plan's nominal; central: its -eps partner, the next
+// lane) and writes its Jacobian column; the nominal lane writes the nominal outputs.
+template <class M>
+__device__ __forceinline__ void wave_outputs(const double *o, const int t, const int64_t unit, const int p, const int idx,
+                                             const bool minus, const int nom, const bool primary, const bool live,
+                                             const bool planned, const bool central, int64_t N, double eps,
+                                             double *__restrict__ dsds, double *__restrict__ dsda, double *__restrict__ drds,
+                                             double *__restrict__ drda, double *__restrict__ s_next,
+                                             double *__restrict__ qpos_next, double *__restrict__ qvel_next,
+                                             double *__restrict__ reward, const char *__restrict__ plan) {
+    constexpr int NV = M::NV, NU = M::NU, NS = 2 * NV, ROW = NS + 1;
     // ---- Jacobian columns: every perturbed lane differences its own result against the reference lane of its
     // unit in THIS wave (forward: the nominal; central: its -eps partner, the next lane) and writes its column.
     // Lanes of one unit hold consecutive columns, so the stores of a wave fall in runs of nu / nv / nq doubles.
@@ -267,18 +248,6 @@ __device__ __forceinline__ unsigned wave_rollouts(double *lds, const int t, cons
         }
         if (reward) reward[unit] = o[NS];
     }
-    unsigned all = 0;
-    if (FIX) {
-        // the fix-up wave owns the whole unit: it REPLACES the word the fast launch left (overflow_kernel stores it)
-#pragma unroll
-        for (int b = 0; b < 5; b++)
-            if (__builtin_amdgcn_ballot_w64(live && ((st >> b) & 1u))) all |= 1u << b;
-    } else {
-        // status: OR over the unit's rollouts; a unit can live in two waves, so it is accumulated in HBM (zeroed by the host)
-        if (status && live && st) atomicOr(&status[unit], st);
-    }
-    MBRL_STAMP(3);
-    return all;
 }
 
 // STEP_NAME only gives plain-step launches their own symbol in profiler output (the body does not use it,
@@ -288,8 +257,16 @@ __device__ __forceinline__ unsigned wave_rollouts(double *lds, const int t, cons
 #else
 #define MBRL_KERNEL_ATTR
 #endif
+constexpr int MODE_MASK = 3, MODE_NO_REDO = 8;   // mode argument: MODE_* | flags
+// Units with more floor contacts than the 8 slots of the fast rollouts are re-run with one slot per floor candidate:
+// either by the wave that found them, right away (Walker2d: walkers that lie flat turn up in most batches, and a
+// planned launch starts them first, so the second run hides under the rest of the launch), or by a fix-up launch
+// afterwards (HalfCheetah: never seen on trajectories, and the wide code inside the fast kernels cost the pipelined
+// bench 1.6 %; the fix-up launch costs it 0.2 %).  profiles/r02_experiments.md has the measurements.
+template <class M> constexpr bool kRedoInWave = M::ENV_ID == 4;
+template <class M> constexpr bool kNeedsRedo = (Layout<M>::NCAND > Layout<M>::K);
 template <class M, bool STEP_NAME>
-__global__ __launch_bounds__(kBlock) MBRL_KERNEL_ATTR void rollout_kernel(int64_t N, int frame_skip, int nsteps, double eps, int mode,
+__global__ __launch_bounds__(kBlock) MBRL_KERNEL_ATTR void rollout_kernel(int64_t N, int frame_skip, int nsteps, double eps, int mode_arg,
                                                           const double *__restrict__ qpos,
                                                           const double *__restrict__ qvel,
                                                           const double *__restrict__ ctrl,
@@ -305,6 +282,7 @@ __global__ __launch_bounds__(kBlock) MBRL_KERNEL_ATTR void rollout_kernel(int64_
     static_assert(1 + 2 * NP <= kBlock, "a unit's rollouts must fit one wave");
     __shared__ double lds[LY::NMEM * kBlock];   // lane columns
 
+    const int mode = mode_arg & MODE_MASK;
     const bool central = mode == MODE_CENTRAL;
     const WaveMap wm(mode == MODE_STEP ? 1 : (central ? 1 + 2 * NP : 1 + NP), central);
     const int t = threadIdx.x;
@@ -343,15 +321,71 @@ __global__ __launch_bounds__(kBlock) MBRL_KERNEL_ATTR void rollout_kernel(int64_
         unit = int64_t(blockIdx.x >> 1) * wm.upp + u;
         live = mapped && unit < N;
     }
-    wave_rollouts<M, 8, false, kBlock>(lds, t, unit, p, nom, primary, live, planned, N, frame_skip, nsteps, eps, mode, qpos, qvel, ctrl,
-                               ctrl_pert, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward, status, plan, plan_mode);
+    MBRL_STAMP(0);
+    double o[ROW];
+    unsigned st = 0;
+    uint64_t key = 0;
+    int idx = -1;            // perturbed input (ctrl, qvel, qpos order), -1: nominal
+    bool minus = false;      // the -eps member of a central couple
+    double d = eps;
+    if (live && p > 0) {
+        idx = p - 1;
+        if (central) { minus = idx & 1; d = minus ? -eps : eps; idx >>= 1; }
+    }
+    if (live) {
+        lane_rollout<M, 8, kBlock>(lds + t, unit, idx, d, central, minus, frame_skip, nsteps, qpos, qvel, ctrl, ctrl_pert, o, st, key);
+    } else {
+#pragma unroll
+        for (int j = 0; j < ROW; j++) o[j] = 0.0;
+    }
+    // ---- more than eight floor contacts at once (a walker lying flat): the rollout above dropped rows and flagged
+    // itself MBRL_ST_OVERFLOW.  Re-run, in this very wave, every lane of a unit that has such a lane here, with one
+    // contact slot per floor candidate (64-bit row masks).  The wider column is strided for 32 lanes so that it fits
+    // the LDS this workgroup already owns: lanes 0-31 first, then lanes 32-63.  Columns are differenced against a
+    // nominal of the same wave, hence of the same kind; a planned launch's nominal comes from the plan, whose own launch
+    // did the same.  Costs the wave a second (slower) set of rollouts -- planned launches start such units first (they
+    // carry the largest keys), so it hides under the rest of the launch; callers never see the flag.
+    if constexpr (kNeedsRedo<M> && kRedoInWave<M>) {
+        unsigned long long need = __builtin_amdgcn_ballot_w64(live && (st & ST_OVERFLOW));
+        if (MBRL_RARE(need != 0 && !(mode_arg & MODE_NO_REDO))) {
+            constexpr int KALL = 32, LANES = 32;                  // Layout clamps KALL to the number of floor candidates
+            static_assert(Layout<M, KALL>::NMEM * LANES <= LY::NMEM * kBlock, "the wide columns must fit this workgroup's LDS");
+            bool redo = false;
+            while (need) {                                        // wave-uniform loop over the flagged lanes
+                const int l = __builtin_ctzll(need);
+                need &= need - 1;
+                const int64_t ul = __shfl(unit, l, 64);
+                redo = redo || (live && unit == ul);
+            }
+            for (int c = 0; c < 2; c++) {
+                const bool mine = redo && (t >> 5) == c;
+                if (__builtin_amdgcn_ballot_w64(mine) == 0) continue;
+                if (mine)
+                    lane_rollout<M, KALL, LANES>(lds + (t & 31), unit, idx, d, central, minus, frame_skip, nsteps, qpos, qvel, ctrl,
+                                                 ctrl_pert, o, st, key);
+            }
+        }
+    }
+    if (live && (plan_mode == PLAN_WRITE || plan_mode == PLAN_RECORD)) {
+        // (the key segment starts at a fixed offset, so a step launch that records into a larger plan gets the
+        // buffer pointer advanced by its unit offset and needs to know nothing else about that plan)
+        const PlanOffsets po(N, NS);
+        reinterpret_cast<uint64_t *>(plan + po.key_in)[unit] = key;
+        if (plan_mode == PLAN_WRITE) reinterpret_cast<uint32_t *>(plan + po.idx_in)[unit] = uint32_t(unit);
+    }
+    MBRL_STAMP(1);
+    MBRL_STAMP(2);
+    wave_outputs<M>(o, t, unit, p, idx, minus, nom, primary, live, planned, central, N, eps, dsds, dsda, drds, drda, s_next,
+                    qpos_next, qvel_next, reward, plan);
+    // status: OR over the unit's rollouts; a unit can live in two waves, so it is accumulated in HBM (zeroed by the host)
+    if (status && live && st) atomicOr(&status[unit], st);
+    MBRL_STAMP(3);
 }
 
-// Fix-up of the units the fast kernel flagged MBRL_ST_OVERFLOW (more than 8 capsule ends on the floor at once: a walker
-// lying flat).  Same rollouts with one contact slot per floor candidate.  Each wave scans a slice of the status words
-// and, for every flagged unit it finds, runs ALL of that unit's rollouts itself and overwrites the unit's outputs, plan
-// entries and status word.  Launched after every rollout launch of a model with more than 8 floor candidates; with
-// nothing flagged it reads N status words and exits.
+// Fix-up launch for models that do not re-run in the wave (kRedoInWave): each wave scans a slice of the status words
+// and, for every unit flagged MBRL_ST_OVERFLOW, runs ALL of that unit's rollouts itself with one contact slot per floor
+// candidate and overwrites the unit's outputs, plan entries and status word.  Launched after every rollout launch of
+// such a model; with nothing flagged it reads N status words and exits.
 // The wider column must not make the workgroup harder to place than a fast-kernel wave: a launch on a second stream
 // competes with those for the slots they free (measured with 59 KB per workgroup: the dispatcher held CUs half empty
 // until two waves had drained, and the pipelined bench lost 2 %).  So the column is strided for 32 lanes, not 64 --
@@ -371,9 +405,8 @@ __global__ __launch_bounds__(kBlock) void overflow_kernel(int64_t N, int frame_s
     constexpr int KALL = 32;                       // Layout clamps it to the number of floor candidates
     constexpr int LANES = 32;
     using LY = Layout<M, KALL>;
-    constexpr int NP = M::NU + 2 * M::NV;
-    static_assert(LY::NMEM * LANES * sizeof(double) <= Layout<M>::NMEM * kBlock * sizeof(double),
-                  "the fix-up workgroup must fit wherever a fast-kernel wave fits");
+    constexpr int NV = M::NV, NS = 2 * NV, ROW = NS + 1, NP = M::NU + 2 * NV;
+    static_assert(LY::NMEM * LANES <= Layout<M>::NMEM * kBlock, "the fix-up workgroup must fit wherever a fast-kernel wave fits");
     __shared__ double lds[LY::NMEM * LANES];
     const bool central = mode == MODE_CENTRAL;
     const int P = mode == MODE_STEP ? 0 : (central ? 2 * NP : NP);      // perturbed rollouts per unit
@@ -385,16 +418,40 @@ __global__ __launch_bounds__(kBlock) void overflow_kernel(int64_t N, int frame_s
         while (pend) {                             // wave-uniform: every lane sees the same ballot
             const int l = __builtin_ctzll(pend);
             pend &= pend - 1;
+            const int64_t unit = base + l;
             unsigned all = 0;
             int off = 0;
             do {
                 const int cnt = P - off < cap ? P - off : cap;
-                all |= wave_rollouts<M, KALL, true, LANES>(lds, t, base + l, t == 0 ? 0 : off + t, 0, true, t <= cnt, false, N,
-                                                           frame_skip, nsteps, eps, mode, qpos, qvel, ctrl, ctrl_pert, dsds, dsda,
-                                                           drds, drda, s_next, qpos_next, qvel_next, reward, status, plan, plan_mode);
+                const bool live = t <= cnt;
+                const int p = t == 0 ? 0 : off + t;
+                double o[ROW];
+                unsigned st = 0;
+                uint64_t key = 0;
+                int idx = -1;
+                bool minus = false;
+                double d = eps;
+                if (live && p > 0) {
+                    idx = p - 1;
+                    if (central) { minus = idx & 1; d = minus ? -eps : eps; idx >>= 1; }
+                }
+                if (live) {
+                    lane_rollout<M, KALL, LANES>(lds + t, unit, idx, d, central, minus, frame_skip, nsteps, qpos, qvel, ctrl,
+                                                 ctrl_pert, o, st, key);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < ROW; j++) o[j] = 0.0;
+                }
+                if (live && p == 0 && (plan_mode == PLAN_WRITE || plan_mode == PLAN_RECORD))
+                    reinterpret_cast<uint64_t *>(plan + PlanOffsets(N, NS).key_in)[unit] = key;
+                wave_outputs<M>(o, t, unit, p, idx, minus, 0, true, live, false, central, N, eps, dsds, dsda, drds, drda, s_next,
+                                qpos_next, qvel_next, reward, plan);
+#pragma unroll
+                for (int b = 0; b < 5; b++)
+                    if (__builtin_amdgcn_ballot_w64(live && ((st >> b) & 1u))) all |= 1u << b;
                 off += cnt;
             } while (off < P);
-            if (t == 0) status[base + l] = all;
+            if (t == 0) status[unit] = all;        // REPLACES the word the fast launch left
         }
     }
 }
@@ -545,20 +602,20 @@ static int launch_rollouts(const mbrl_model *m, int64_t N, int mode, const doubl
     // per-unit status words are OR-ed into HBM by the waves (a unit can span two): start from zero, in stream order
     // (a planned launch ORs into the words its plan launch wrote)
     if (status && !planned && hipMemsetAsync(status, 0, sizeof(uint32_t) * size_t(N), st) != hipSuccess) return -1;
+    // (MBRL_NO_OVERFLOW_REDO in the environment: tests use it to see the flags the 8-slot rollouts raise)
+    const int mode_arg = mode | (getenv("MBRL_NO_OVERFLOW_REDO") ? MODE_NO_REDO : 0);
     if (mode == MODE_STEP)
         hipLaunchKernelGGL((rollout_kernel<M, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, N, m->frame_skip, nsteps,
-                           eps, mode, qpos, qvel, ctrl, ctrl_pert, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward,
+                           eps, mode_arg, qpos, qvel, ctrl, ctrl_pert, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward,
                            status, plan, plan_mode);
     else
         hipLaunchKernelGGL((rollout_kernel<M, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, N, m->frame_skip, nsteps,
-                           eps, mode, qpos, qvel, ctrl, ctrl_pert, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward,
+                           eps, mode_arg, qpos, qvel, ctrl, ctrl_pert, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward,
                            status, plan, plan_mode);
-    // Models with more floor candidates than the fast kernel has contact slots: re-run whatever it flagged
-    // MBRL_ST_OVERFLOW with one slot per candidate (overflow_kernel).  A planned launch's flagged units are redone whole,
-    // nominal included, so the fix-up needs no plan; plan and record launches re-record their units' plan entries.
-    // (MBRL_NO_OVERFLOW_FIXUP in the environment skips it: tests use that to see the flags the fast kernel raises.)
-    if constexpr ((Layout<M>::NCAND > Layout<M>::K)) {
-        if (status && !getenv("MBRL_NO_OVERFLOW_FIXUP")) {
+    if constexpr (kNeedsRedo<M> && !kRedoInWave<M>) {
+        // fix-up launch (overflow_kernel).  A planned launch's flagged units are redone whole, nominal included, so it
+        // needs no plan; plan and record launches re-record their units' keys.
+        if (status && !(mode_arg & MODE_NO_REDO)) {
             int64_t fb = (N + kBlock - 1) / kBlock;
             if (fb > 1024) fb = 1024;
             hipLaunchKernelGGL((overflow_kernel<M>), dim3((unsigned)fb), dim3(kBlock), 0, st, N, m->frame_skip, nsteps, eps, mode,

@@ -4,6 +4,7 @@ PyTorch is plumbing here (HBM allocation, streams); all arithmetic happens in th
 kernels behind include/mbrl.h.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -72,7 +73,7 @@ class FdEngine:
         """A second HIP stream of this engine's device (rollout.Linearisation overlaps the FD launches with the serial
         step launches on it)."""
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("MBRL_SIDE_PRIORITY", "0")))
         return self._side
 
     def _new(self, *shape, dtype=torch.float64):

@@ -43,11 +43,11 @@ def test_units_with_more_than_eight_contacts_are_fixed_up(env):
     N = 96
     q, v, c = flat_states(env, N, 3)
     # the states do overflow the fast kernel (seen with the fix-up switched off) ...
-    os.environ["MBRL_NO_OVERFLOW_FIXUP"] = "1"
+    os.environ["MBRL_NO_OVERFLOW_REDO"] = "1"
     try:
         raw = e.step(q, v, c)[3].cpu().numpy()
     finally:
-        del os.environ["MBRL_NO_OVERFLOW_FIXUP"]
+        del os.environ["MBRL_NO_OVERFLOW_REDO"]
     assert ((raw & 4) != 0).sum() >= N // 8, int(((raw & 4) != 0).sum())
     # ... and the caller never sees it: env.step
     qo, vo, ro, so = o.step(q, v, c, nthreads=8)
