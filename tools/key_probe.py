@@ -82,19 +82,27 @@ use(lex([union, h1, h2] + P_), "union, halves, passes")
 use(lex([tot // 4, union] + P_), "total passes / 4, union, passes")
 use(lex([tot // 8, union, tot] + P_), "total passes / 8, union, total, passes")
 use(lex([ncon // 4, union, tot] + P_), "constrained steps / 4, union, total, passes")
-code2 = np.clip(ps - 1, 0, 3)          # 2 bits per step: 0/1 passes, 2, 3, 4+
-code1 = (ps > 0).astype(np.int64)
-C2 = [code2[:, k] for k in range(T)]
-C1 = [code1[:, k] for k in range(T)]
-for d in (2, 4, 8):
-    use(lex([tot // d, union] + C2), "total / %d, union, 2-bit codes" % d)
-use(lex([tot // 4, union] + C1), "total / 4, union, 1-bit codes")
-use(lex([tot // 4, union] + C2[:18]), "total / 4, union, 2-bit codes of the first 18 steps")
-use(lex([tot // 4, union] + C2[:12]), "total / 4, union, 2-bit codes of the first 12 steps")
-use(lex([tot // 4, union]), "total / 4, union")
-use(lex([tot // 4, pc(union), union] + C2), "total / 4, popcount(union), union, 2-bit codes")
-use(lex([tot // 4, union, h1] + C2), "total / 4, union, first-half union, 2-bit codes")
-cst = np.clip(ps, 0, 7)
-use(lex([cst.sum(1) // 4, union] + C2), "total of capped passes / 4, union, 2-bit codes")
+def snake(cols, base):
+    """reflected (boustrophedon) order: a digit runs backwards whenever the digits above it sum to an odd number, so
+    neighbours across a carry differ in one digit only"""
+    out, par = [], np.zeros(N, dtype=np.int64)
+    for c in cols:
+        c = np.minimum(c, base - 1)
+        out.append(np.where(par & 1, base - 1 - c, c))
+        par = par + c
+    return out
+L_ = [ls[:, k] for k in range(T)]
+use(lex(P_ + L_), "passes, then line evals (the kernel's short-rollout key)")
+use(lex([x for k in range(T) for x in (ps[:, k], ls[:, k])]), "per step (passes, line evals)")
+use(lex(P_ + [rows[:, k] for k in range(T)]), "passes, then rows per step")
+use(lex(P_ + L_ + [rows[:, k] for k in range(T)]), "passes, line evals, rows per step")
+use(lex(list(reversed(P_)) + list(reversed(L_))), "time-reversed passes, line evals")
+use(lex(snake(P_, 8) + L_), "snake(passes), line evals")
+use(lex(snake(P_ + L_, 8)), "snake(passes, line evals)")
+use(lex([ncon] + P_ + L_), "constrained steps, passes, line evals")
+use(lex([ps.max(1)] + P_ + L_), "max passes, passes, line evals")
+cost = ps + 0.3 * ls
+use(lex([np.round(cost.sum(1)).astype(np.int64)] + P_ + L_), "estimated cost, passes, line evals")
+use(lex([np.round(cost.sum(1) / 4).astype(np.int64)] + P_ + L_), "estimated cost / 4, passes, line evals")
 perm_view.copy_(own)
 print("%-52s %.3f ms" % ("kernel's own key again", timed()))
