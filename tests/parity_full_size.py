@@ -15,12 +15,13 @@ from oracle import Oracle
 
 env = sys.argv[1] if len(sys.argv) > 1 else "HalfCheetahEnv"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 163840
+fd_mode = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # 0 forward (reference parity), 1 central
 e, o = FdEngine(env), Oracle(env)
 q, v, c = workloads.s2(e, N, seed=0, horizon=40)
-out = {k: t.cpu().numpy() for k, t in e.fd_jacobians(q, v, c, planned=True).items()}
+out = {k: t.cpu().numpy() for k, t in e.fd_jacobians(q, v, c, fd_mode=fd_mode, planned=True).items()}
 t0 = time.time()
-ref = o.fd_jacobians(q.cpu().numpy(), v.cpu().numpy(), c.cpu().numpy(), nthreads=16)
-print("%s: %d units, oracle %.1f s on 16 threads" % (env, N, time.time() - t0), flush=True)
+ref = o.fd_jacobians(q.cpu().numpy(), v.cpu().numpy(), c.cpu().numpy(), fd_mode=fd_mode, nthreads=16)
+print("%s, %s differences: %d units, oracle %.1f s on 16 threads" % (env, "central" if fd_mode else "forward", N, time.time() - t0), flush=True)
 print("status words equal: %s; flagged units: %d" % (bool((out["status"] == ref["status"].astype(np.int32)).all()),
                                                       int((ref["status"] != 0).sum())))
 ok = ref["status"] == 0

@@ -36,7 +36,7 @@ def test_hostile_states_step_matches_oracle(env):
     assert err.max() < 1e-9, (env, float(err.max()))
 
 
-@pytest.mark.parametrize("env", ["HalfCheetahEnv", "HopperEnv"])
+@pytest.mark.parametrize("env", ["HalfCheetahEnv", "HopperEnv", "Walker2dEnv"])
 def test_hostile_states_linearise_without_fault(env):
     """The FD launches (both schedules) on the same kind of input: equal bits between the schedules, status words
     equal to the oracle's, finite Jacobians wherever no rollout of the unit was flagged."""
