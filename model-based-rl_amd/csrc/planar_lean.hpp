@@ -80,10 +80,14 @@ constexpr int kMaxLineSearch = 40;
 // The first Newton iterations take the full step without a line search (measured on on-trajectory HalfCheetah
 // states, per wave and mj_step: 1.9 passes + 3.0 line evaluations with the search from the start, 2.7 + 0.2 with
 // two full steps first).  The minimum is unique and every exit tests the active set, so the path does not matter.
-#ifndef MBRL_UNIT_ITERS
-#define MBRL_UNIT_ITERS 2
+// How many: 2 for HalfCheetah (1 is 1 % slower, 3 .. 8 within noise); 4 for the long rollouts of Hopper and Walker2d,
+// whose contact sets change more per solve (perturbed rollouts 2-3 % faster, the nominal launch 6-10 %;
+// profiles/r02_experiments.md).  -DMBRL_UNIT_ITERS=n overrides it for every model (A/B builds).
+#ifdef MBRL_UNIT_ITERS
+template <class M> constexpr int kUnitIters = MBRL_UNIT_ITERS;
+#else
+template <class M> constexpr int kUnitIters = (M::ENV_ID == 3 || M::ENV_ID == 4) ? 4 : 2;
 #endif
-constexpr int kUnitIters = MBRL_UNIT_ITERS;
 
 // ---- scalar helpers (overloaded by the host-side counting type) ----
 MBRL_HD double t_abs(double x) { return fabs(x); }
@@ -1144,7 +1148,7 @@ struct Lean {
             for (int j = 0; j < NV; j++) a2 = a2 + sx[j] * Ms[j];
             MBRL_PIN(Ms, NV);
             MBRL_PHASE(4);
-            if (it < kUnitIters) {
+            if (it < kUnitIters<M>) {
                 MBRL_UNROLL
                 for (int j = 0; j < NV; j++) { qacc[j] = qacc[j] + sx[j]; gs[j] = gs[j] + Ms[j]; }
                 return false;
