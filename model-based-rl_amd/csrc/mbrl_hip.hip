@@ -259,11 +259,15 @@ __device__ __forceinline__ void wave_outputs(const double *o, const int t, const
 #endif
 constexpr int MODE_MASK = 3, MODE_NO_REDO = 8;   // mode argument: MODE_* | flags
 // Units with more floor contacts than the 8 slots of the fast rollouts are re-run with one slot per floor candidate:
-// either by the wave that found them, right away (Walker2d: walkers that lie flat turn up in most batches, and a
-// planned launch starts them first, so the second run hides under the rest of the launch), or by a fix-up launch
-// afterwards (HalfCheetah: never seen on trajectories, and the wide code inside the fast kernels cost the pipelined
-// bench 1.6 %; the fix-up launch costs it 0.2 %).  profiles/r02_experiments.md has the measurements.
-template <class M> constexpr bool kRedoInWave = M::ENV_ID == 4;
+// either by the wave that found them, right away, or by a fix-up launch afterwards (overflow_kernel).  Measured
+// (profiles/r02_experiments.md):
+//   * Walker2d: in the wave, everywhere.  Walkers that lie flat turn up in most batches, and a planned launch starts
+//     them first, so the second run hides under the rest of the launch (a fix-up launch costs one serial wave-time of a
+//     flat walker, 2.65 ms, with the chip idle).
+//   * HalfCheetah: in the wave for step / plan launches (STEP_NAME kernels: no extra launch after each of a rollout's
+//     40 step launches, 1 ms per training epoch), a fix-up launch after the FD launches (never needed on trajectories;
+//     the wide code inside the FD kernel cost the pipelined bench 1.7 %, the fix-up launch costs it 0.2 %).
+template <class M, bool STEP_NAME> constexpr bool kRedoInWave = M::ENV_ID == 4 || STEP_NAME;
 template <class M> constexpr bool kNeedsRedo = (Layout<M>::NCAND > Layout<M>::K);
 template <class M, bool STEP_NAME>
 __global__ __launch_bounds__(kBlock) MBRL_KERNEL_ATTR void rollout_kernel(int64_t N, int frame_skip, int nsteps, double eps, int mode_arg,
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(kBlock) MBRL_KERNEL_ATTR void rollout_kernel(int64_
     // nominal of the same wave, hence of the same kind; a planned launch's nominal comes from the plan, whose own launch
     // did the same.  Costs the wave a second (slower) set of rollouts -- planned launches start such units first (they
     // carry the largest keys), so it hides under the rest of the launch; callers never see the flag.
-    if constexpr (kNeedsRedo<M> && kRedoInWave<M>) {
+    if constexpr (kNeedsRedo<M> && kRedoInWave<M, STEP_NAME>) {
         unsigned long long need = __builtin_amdgcn_ballot_w64(live && (st & ST_OVERFLOW));
         if (MBRL_RARE(need != 0 && !(mode_arg & MODE_NO_REDO))) {
             constexpr int KALL = 32, LANES = 32;                  // Layout clamps KALL to the number of floor candidates
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(kBlock) MBRL_KERNEL_ATTR void rollout_kernel(int64_
     MBRL_STAMP(3);
 }
 
-// Fix-up launch for models that do not re-run in the wave (kRedoInWave): each wave scans a slice of the status words
+// Fix-up launch for FD launches of models that do not re-run in the wave (kRedoInWave): each wave scans a slice of the status words
 // and, for every unit flagged MBRL_ST_OVERFLOW, runs ALL of that unit's rollouts itself with one contact slot per floor
 // candidate and overwrites the unit's outputs, plan entries and status word.  Launched after every rollout launch of
 // such a model; with nothing flagged it reads N status words and exits.
@@ -612,7 +616,8 @@ static int launch_rollouts(const mbrl_model *m, int64_t N, int mode, const doubl
         hipLaunchKernelGGL((rollout_kernel<M, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, N, m->frame_skip, nsteps,
                            eps, mode_arg, qpos, qvel, ctrl, ctrl_pert, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward,
                            status, plan, plan_mode);
-    if constexpr (kNeedsRedo<M> && !kRedoInWave<M>) {
+    if constexpr (kNeedsRedo<M> && !kRedoInWave<M, false>) {
+      if (mode != MODE_STEP)   // step / plan launches (rollout_kernel<M, true>) re-run in the wave
         // fix-up launch (overflow_kernel).  A planned launch's flagged units are redone whole, nominal included, so it
         // needs no plan; plan and record launches re-record their units' keys.
         if (status && !(mode_arg & MODE_NO_REDO)) {

@@ -66,6 +66,9 @@ def test_units_with_more_than_eight_contacts_are_fixed_up(env):
         for k in a:
             assert torch.equal(a[k], b[k]), (k, fd_mode)
         assert int(a["status"].abs().sum()) == 0 and (ref["status"] == 0).all()
+        # the nominal rollout of a linearisation is the step launch's, bit for bit (the reference asserts it,
+        # backward.py:371,374) -- also where the two are re-run by different means (in the wave / by the fix-up launch)
+        assert torch.equal(a["s_next"], torch.cat([qn, vn], 1)) and torch.equal(a["reward"], r), fd_mode
         for k in ("dsds", "dsda", "drds", "drda"):
             x, y = a[k].cpu().numpy().reshape(N, -1), ref[k].reshape(N, -1)
             rel = np.abs(x - y).max(axis=1) / (1.0 + np.abs(y).max(axis=1))
