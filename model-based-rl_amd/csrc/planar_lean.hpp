@@ -1193,7 +1193,11 @@ struct Lean {
         // Same arithmetic either way; measured per model (profiles/r02_experiments.md, 65 536 units): Hopper gains 6 % with
         // two peeled iterations, HalfCheetah and Walker2d lose 2-4 % (larger kernels: the copies cost more than the
         // loop's register shuffle), so only Hopper peels.
+#ifdef MBRL_PEEL
+        constexpr int kPeel = MBRL_PEEL;                     // A/B builds
+#else
         constexpr int kPeel = (M::ENV_ID == 3) ? 2 : 0;
+#endif
         bool done = false;
         MBRL_UNROLL
         for (int it = 0; it < kPeel; it++)
