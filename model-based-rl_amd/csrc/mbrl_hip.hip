@@ -460,6 +460,12 @@ __global__ __launch_bounds__(kBlock) void overflow_kernel(int64_t N, int frame_s
     }
 }
 
+// status words start from zero (the rollout waves OR into them)
+__global__ __launch_bounds__(256) void zero_words_kernel(uint32_t *__restrict__ w, int64_t n) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n) w[i] = 0u;
+}
+
 // mbrl_fd_plan_finish: header and identity order of a plan whose keys and nominal results were recorded by step launches.
 __global__ __launch_bounds__(256) void plan_finish_kernel(int64_t N, int nsteps, int frame_skip, int env_id, int ns,
                                                            char *__restrict__ plan) {
@@ -605,7 +611,10 @@ static int launch_rollouts(const mbrl_model *m, int64_t N, int mode, const doubl
     if (blocks > 0x7fffffffLL) return -2;
     // per-unit status words are OR-ed into HBM by the waves (a unit can span two): start from zero, in stream order
     // (a planned launch ORs into the words its plan launch wrote)
-    if (status && !planned && hipMemsetAsync(status, 0, sizeof(uint32_t) * size_t(N), st) != hipSuccess) return -1;
+    // (a kernel, not hipMemsetAsync: replayed from a captured HIP graph, the memset node left garbage in the words from
+    // the second replay on -- ROCm 7.2; tests/test_zz_no_alloc.py replays mbrl_fd_jacobians_static three times)
+    if (status && !planned)
+        hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, status, N);
     // (MBRL_NO_OVERFLOW_REDO in the environment: tests use it to see the flags the 8-slot rollouts raise)
     const int mode_arg = mode | (getenv("MBRL_NO_OVERFLOW_REDO") ? MODE_NO_REDO : 0);
     if (mode == MODE_STEP)

@@ -64,3 +64,41 @@ def test_static_rejects_batches_beyond_its_scratch_and_allocates_nothing():
     torch.cuda.synchronize()
     assert torch.cuda.mem_get_info()[0] == free0
     assert int((o["status"] != 0).sum()) == 0
+
+
+def test_static_entry_point_replays_from_a_captured_hip_graph():
+    """What the entry point is for: a caller under HIP graph capture.  The call is captured once (torch.cuda.CUDAGraph)
+    and replayed three times on two different batches written into the graph's input buffers; every replay gives the
+    bits of mbrl_fd_jacobians.  (The status words are cleared by a kernel: a captured hipMemsetAsync left garbage in
+    them from the second replay on.)"""
+    import torch
+    import mbrl_amd  # noqa: F401
+    from mbrl_amd import workloads
+    from mbrl_amd.engine import FdEngine
+    e = FdEngine("HalfCheetahEnv")
+    N = 2048
+    p = lambda t: C.c_void_p(t.data_ptr())
+    qa, va, ca = workloads.s2(e, N, seed=1, horizon=8)
+    qb, vb, cb = workloads.s2(e, N, seed=2, horizon=8)
+    q, v, c = qa.clone(), va.clone(), ca.clone()          # the graph's input buffers
+    o = e.new_outputs(N)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                         # first use outside the capture (lazy module loading)
+        assert _call(e.L.mbrl_fd_jacobians_static, e, q, v, c, 0, 1, o) == 0
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        assert _call(e.L.mbrl_fd_jacobians_static, e, q, v, c, 0, 1, o) == 0, e.L.mbrl_last_error()
+    for qq, vv, cc in ((qb, vb, cb), (qa, va, ca), (qb, vb, cb)):
+        q.copy_(qq); v.copy_(vv); c.copy_(cc)
+        for k in NAMES:
+            o[k].fill_(7)
+        g.replay()
+        torch.cuda.synchronize()
+        ref = e.new_outputs(N)
+        assert _call(e.L.mbrl_fd_jacobians, e, qq, vv, cc, 0, 1, ref) == 0
+        torch.cuda.synchronize()
+        for k in NAMES:
+            assert torch.equal(ref[k], o[k]), k
