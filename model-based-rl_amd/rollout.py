@@ -225,12 +225,19 @@ def rollout_with_policy(engine, agent, model_policy, s0, horizon, linearise=None
     B = Q.shape[1]
     A = torch.empty((horizon, B, engine.nu), dtype=torch.float64, device=engine.device)
     lin = Linearisation(engine, B, horizon, **linearise) if linearise else None
+    # an open-loop policy's actions do not depend on the states: all of them at once, so that nothing but the step
+    # launches sits between two env steps (strategies.forward_open_loop; None: ask the policy step by step)
+    ahead = getattr(model_policy, "forward_open_loop", None)
+    ahead = ahead(horizon, B) if ahead is not None and os.environ.get("MBRL_NO_ACTIONS_AHEAD") is None else None
+    if ahead is not None:
+        A.copy_(ahead.detach())
     acts = []
     for t in range(horizon):
         agent.set_step_idx(t)
-        a = model_policy(torch.cat([Q[t], V[t]], dim=1).float()).double()
-        acts.append(a)
-        A[t].copy_(a.detach())
+        if ahead is None:
+            a = model_policy(torch.cat([Q[t], V[t]], dim=1).float()).double()
+            acts.append(a)
+            A[t].copy_(a.detach())
         rec = lin.recorder(t) if lin is not None else None
         if rec is not None:
             engine.step_record(Q[t], V[t], A[t], Q[t + 1], V[t + 1], R[t], S[t], *rec)
@@ -244,4 +251,5 @@ def rollout_with_policy(engine, agent, model_policy, s0, horizon, linearise=None
     agent.set_step_idx(horizon)
     if lin is not None:
         lin.keep = (Q, V, A)     # the side stream reads these: they live as long as the linearisation does
-    return states, torch.stack(acts, dim=1), rewards, status, lin
+    actions = ahead.permute(1, 0, 2) if ahead is not None else torch.stack(acts, dim=1)
+    return states, actions, rewards, status, lin

@@ -165,6 +165,31 @@ class VariationalOptimization(nn.Module):
                 self.log_prob[e, t] = dist.log_prob(a).sum()
         return action
 
+    def forward_open_loop(self, horizon, batch):
+        """All `horizon` forward() calls of one batched training rollout at once, for an open-loop policy (the actions
+        do not depend on the states): the same noise draws in the same order, the same arithmetic per element, the same
+        side effects (`_clamped_action`, `log_prob`) -- but a dozen kernels per epoch instead of a dozen per env step,
+        so the rollout's step launches run back to back.  Returns actions [horizon, batch, action_dim] (with their graph
+        to `mean` and `sd`), or None when the per-step path has to be taken (closed-loop policy, evaluation mode, a
+        batch of one, a non-positive standard deviation somewhere)."""
+        if self.cfg.MODEL.POLICY.NETWORK or not self.training or self.batch_size <= 1:
+            return None
+        if horizon != self.horizon or batch != self.local_batch:
+            return None
+        if not all(self._sd_is_positive(t) for t in range(horizon)):
+            return None
+        z = torch.stack([torch.randn((self.batch_size, self.action_dim), dtype=torch.float64, device=self.device,
+                                     generator=self.noise_gen)[self.shard[0]:self.shard[1]][:batch]
+                         for _ in range(horizon)])                                      # [H, B, nu], forward()'s draws
+        mean = self.mean.T[:, None, :].expand(horizon, batch, self.action_dim)          # mean[:, t] per step
+        sd = self.clamp_sd(self.sd).T[:, None, :]                                       # clamp_sd(sd[:, t]) per step
+        action = mean + sd * z
+        a = action.detach()
+        self._clamped_action[:, :, :batch] = a.permute(2, 0, 1)
+        dist = torch.distributions.Normal(mean, sd, validate_args=False)
+        self.log_prob[:batch, :] = dist.log_prob(a).sum(dim=-1).T
+        return action
+
     # ---- losses (strategies.py:129-280) ----
     def calculate_reinforce_loss(self, batch_loss, stepwise_loss=False):
         returns = torch.empty_like(batch_loss)

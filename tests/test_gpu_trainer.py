@@ -337,3 +337,24 @@ def test_fused_schedule_honours_nsteps_for_backward(overlap, tmp_path):
     for k in res["fused"]:
         assert torch.allclose(res["fused"][k], res["ops"][k], rtol=1e-6, atol=1e-9), k
     assert any(not torch.allclose(res["fused"][k], v.cpu(), rtol=1e-6, atol=1e-9) for k, v in one.policy_net.state_dict().items())
+
+
+def test_actions_ahead_of_the_rollout_train_bit_for_bit(tmp_path, monkeypatch):
+    """An open-loop policy's actions for the whole horizon are drawn before the rollout (strategies.forward_open_loop:
+    the rollout's step launches then run back to back) -- same noise, same arithmetic: the parameters after three epochs
+    are those of asking the policy step by step, bit for bit; so are the recorded actions and log-probabilities."""
+    import torch
+    res = {}
+    for ahead in (False, True):
+        if ahead:
+            monkeypatch.delenv("MBRL_NO_ACTIONS_AHEAD", raising=False)
+        else:
+            monkeypatch.setenv("MBRL_NO_ACTIONS_AHEAD", "1")
+        agent, rows, d = _train(_cfg("HalfCheetahEnv", B=24, H=7, epochs=3), tmp_path, "ahead%d" % ahead)
+        pol = agent.policy_net
+        res[ahead] = ({k: v.cpu() for k, v in pol.state_dict().items()}, pol._clamped_action.cpu().clone(),
+                      pol.log_prob.cpu().clone(), rows)
+    for k in res[False][0]:
+        assert torch.equal(res[False][0][k], res[True][0][k]), k
+    assert torch.equal(res[False][1], res[True][1]) and torch.equal(res[False][2], res[True][2])
+    assert res[False][3] == res[True][3]
