@@ -11,7 +11,7 @@ def run(B, epochs):
     cfg = config.get_cfg_defaults()
     cfg.merge_from_file(os.path.join(os.path.dirname(__file__), "..", "configs", "half_cheetah.yaml"))
     cfg.merge_from_list(["MODEL.BATCH_SIZE", str(B), "MODEL.EPOCHS", str(epochs), "LOG.PERIOD", "1000",
-                         "MODEL.FD_OVERLAP_STEPS", os.environ.get("OVERLAP", "8")])
+                         "MODEL.FD_OVERLAP_STEPS", os.environ.get("OVERLAP", "4")])      # 4 = the configuration default
     cfg.freeze()
     d = tempfile.mkdtemp()
     lg = logging.getLogger("quiet%d_%d" % (B, epochs)); lg.setLevel(logging.ERROR)
