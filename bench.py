@@ -171,7 +171,7 @@ def main():
         out = eng.new_outputs(N)
         pipelined = not (a.single_launch or a.serial_plan or serial)
         plans = [eng.new_plan(N) for _ in range(2 if pipelined else 1)]
-        side = eng.side_stream(priority=-1) if pipelined else main_stream
+        side = eng.side_stream() if pipelined else main_stream
         nom = [dict(s_next=out["s_next"], reward=out["reward"], status=eng._new(N, dtype=torch.int32)) for _ in plans]
 
         def plan_on(stream, k):

@@ -69,14 +69,14 @@ class FdEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def side_stream(self, priority=0):
+    def side_stream(self):
         """A second HIP stream of this engine's device (rollout.Linearisation overlaps the FD launches with the serial
-        step launches on it; bench.py runs the next step's plan launch on a high-priority one, -1: its latency-bound
-        waves then get the slots the big kernel frees first, +0.3 %)."""
-        side = self.__dict__.setdefault("_side", {})
-        if priority not in side:
-            side[priority] = torch.cuda.Stream(device=self.device, priority=priority)
-        return side[priority]
+        step launches on it, bench.py the next step's plan launch with the perturbed rollouts).  Default priority: a
+        high-priority stream gained the bench 0.3 %, and with the linearisation on one a training run stopped making
+        progress -- not worth it."""
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     def _new(self, *shape, dtype=torch.float64):
         return torch.empty(shape, dtype=dtype, device=self.device)
