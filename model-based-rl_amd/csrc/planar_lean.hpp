@@ -80,13 +80,15 @@ constexpr int kMaxLineSearch = 40;
 // The first Newton iterations take the full step without a line search (measured on on-trajectory HalfCheetah
 // states, per wave and mj_step: 1.9 passes + 3.0 line evaluations with the search from the start, 2.7 + 0.2 with
 // two full steps first).  The minimum is unique and every exit tests the active set, so the path does not matter.
-// How many: 2 for HalfCheetah (1 is 1 % slower, 3 .. 8 within noise); 4 for the long rollouts of Hopper and Walker2d,
-// whose contact sets change more per solve (perturbed rollouts 2-3 % faster, the nominal launch 6-10 %;
-// profiles/r02_experiments.md).  -DMBRL_UNIT_ITERS=n overrides it for every model (A/B builds).
+// How many: 4 for the three models with floor contacts -- against 2, the perturbed rollouts of Hopper and Walker2d run
+// 2-3 % faster and HalfCheetah's the same, and the nominal / step launches (64 unrelated units per wave, where every
+// line search any lane needs is paid by all) 5-10 % faster: 0.6 ms of a 12.4 ms training epoch (1 is slower everywhere,
+// 6 and 8 no better; profiles/r02_experiments.md).  2 for the models that only have joint limits.
+// -DMBRL_UNIT_ITERS=n overrides it for every model (A/B builds).
 #ifdef MBRL_UNIT_ITERS
 template <class M> constexpr int kUnitIters = MBRL_UNIT_ITERS;
 #else
-template <class M> constexpr int kUnitIters = (M::ENV_ID == 3 || M::ENV_ID == 4) ? 4 : 2;
+template <class M> constexpr int kUnitIters = M::HAS_FLOOR ? 4 : 2;
 #endif
 
 // ---- scalar helpers (overloaded by the host-side counting type) ----
