@@ -75,6 +75,7 @@ def init_distributed(backend=None):
         return "cuda:%d" % local
     dist.init_process_group(backend)
     if torch.cuda.is_available():
+        local %= max(torch.cuda.device_count(), 1)      # rehearsal: more ranks than GPUs share them (as bench.py does)
         torch.cuda.set_device(local)
         return "cuda:%d" % local
     return None
