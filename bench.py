@@ -44,25 +44,22 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the central-difference figures in `extra`")
     ap.add_argument("--single-launch", action="store_true", help="time mbrl_fd_jacobians instead of plan + planned")
+    ap.add_argument("--rank-timeout", type=float, default=None,
+                    help="--gpus N self-launcher: stop every rank after this many seconds (default: MBRL_RANK_TIMEOUT or none)")
     ap.add_argument("--serial-plan", action="store_true",
                     help="plan launch and perturbed rollouts of a step strictly one after the other on one stream "
                          "(default: the plan of step k+1 overlaps the perturbed rollouts of step k on a second stream)")
     return ap.parse_args()
 
 
-def launch_ranks(n):
+def launch_ranks(n, timeout=None):
     """Start n ranks of this script as fresh child processes (this process has not touched the GPU and never will:
-    nothing is exec'ed after HIP initialisation).  Rank 0's stdout is ours; returns the worst exit code."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    return max(p.wait() for p in procs)
+    nothing is exec'ed after HIP initialisation) and supervise them (mbrl_amd/launch.py): the first rank that fails ends
+    the job -- its siblings are stopped instead of waiting in a collective -- and its exit code is returned
+    (128 + signal for a signal death).  Rank 0's stdout is ours."""
+    import mbrl_amd  # noqa: F401  (import shim; no torch, no GPU)
+    from mbrl_amd import launch
+    return launch.launch(n, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], timeout=timeout)
 
 
 def recorded(pattern):
@@ -113,20 +110,28 @@ def cpu_baseline(q, v, c, budget_units):
     t0 = time.perf_counter()
     o.fd_jacobians(q[:n], v[:n], c[:n], nthreads=1)
     t1 = time.perf_counter()
-    cores = min(16, os.cpu_count() or 1)
+    # all-core leg: every core this process may run on (the GPU box gives a one-GPU job a 16-CPU share of a much
+    # larger host; os.cpu_count() reports the whole machine and is printed next to it)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", cores) or cores)))
     m = min(len(q), n * 4)
     t2 = time.perf_counter()
     o.fd_jacobians(q[:m], v[:m], c[:m], nthreads=cores)
     t3 = time.perf_counter()
     return {"value": n / (t1 - t0), "unit": "Jacobians/s", "cores": 1, "kind": "port",
             "sample": "%d HalfCheetah S2 units, oracle/mjc_oracle.c single thread (%.1f s)" % (n, t1 - t0),
-            "all_core_value": m / (t3 - t2), "all_core_threads": cores}
+            "all_core_value": m / (t3 - t2), "all_core_threads": cores, "host_cpu_count": os.cpu_count(),
+            "all_core_note": "threads = the cores this job may use (affinity / OMP_NUM_THREADS share of the box), "
+                             "host_cpu_count = os.cpu_count() of the whole machine"}
 
 
 def main():
     a = parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(a.gpus))
+        sys.exit(launch_ranks(a.gpus, a.rank_timeout))
 
     import numpy as np
     import torch
@@ -134,7 +139,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = world > 1
+    # MBRL_FORCE_DIST=1: go through the process group with ONE rank too -- init_process_group("nccl"), the barriers, the
+    # MAX reduce of the timing -- so that the RCCL branch runs on a one-GPU box exactly as it will on eight
+    force = os.environ.get("MBRL_FORCE_DIST", "") not in ("", "0")
+    dist = world > 1 or force
     # MBRL_DIST_BACKEND=gloo: rehearsal with more ranks than GPUs (ranks share GPUs; RCCL needs a GPU per rank)
     backend = os.environ.get("MBRL_DIST_BACKEND", "nccl")
     if backend != "nccl":
@@ -142,10 +150,16 @@ def main():
     torch.cuda.set_device(local)
     if dist:
         import torch.distributed as td
+        import mbrl_amd  # noqa: F401
+        from mbrl_amd import launch
+        if "MASTER_ADDR" not in os.environ:      # forced single rank without a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(launch.free_port()), RANK="0", WORLD_SIZE="1")
         if backend == "nccl":
-            td.init_process_group("nccl", device_id=torch.device("cuda", local))
+            td.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=launch.init_timeout())
         else:
-            td.init_process_group(backend)
+            td.init_process_group(backend, timeout=launch.init_timeout())
+        for _ in range(3):       # the first collectives set up channels lazily: keep that out of the timed region's barrier
+            td.barrier()
 
     import mbrl_amd  # noqa: F401
     from mbrl_amd import workloads
@@ -271,6 +285,7 @@ def main():
                                    (" (plan of step k+1 on a second stream under the perturbed rollouts of step k)"
                                     if pipelined else ""),
                        "env": ENV, "units_per_gpu": N, "frame_skip": 10, "fd_mode": a.fd_mode,
+                       "side_stream_candidates_rejected": getattr(eng, "side_stream_rejected", None),
                        "parallelism": "units sharded over %d GPU(s), no data-path collective" % world},
             "roofline": {"bound": "valu_fp64", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,

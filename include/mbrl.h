@@ -22,16 +22,18 @@
 extern "C" {
 #endif
 
-#define MBRL_ABI_VERSION 7
+#define MBRL_ABI_VERSION 8
 
 /* per-unit status bits (replace mujoco-py's MujocoException / the reference's asserts,
  * backward.py:371,374) */
 #define MBRL_ST_NONFINITE  1u  /* NaN/Inf state or non-positive pivot */
 #define MBRL_ST_NOCONVERGE 2u  /* constraint solver hit its iteration cap */
-#define MBRL_ST_OVERFLOW   4u  /* internal: more than 8 floor contacts at once.  Callers that pass `status` never see it:
-                                * the entry points re-run such units with full contact capacity */
+#define MBRL_ST_OVERFLOW   4u  /* internal: more than 8 floor contacts at once.  Callers never see it: every entry point
+                                * re-runs such units with full contact capacity, with or without a status array
+                                *  */
 #define MBRL_ST_DEGENERATE 8u  /* reserved; not raised since ABI 6: crossing capsule axes have a defined normal */
-#define MBRL_ST_BADPLAN    16u /* mbrl_fd_jacobians_planned: the plan was made for another batch (N, nsteps, model) */
+#define MBRL_ST_BADPLAN    16u /* mbrl_fd_jacobians_planned: the plan was made for another batch (N, nsteps, model);
+                                * mbrl_fd_jacobians_static: the call overlapped another one on the same GPU */
 
 #define MBRL_FD_FORWARD 0      /* reference parity: one-sided, (f(x+eps)-f(x))/eps, backward.py:402-406 */
 #define MBRL_FD_CENTRAL 1      /* (f(x+eps)-f(x-eps))/(2 eps) */
@@ -65,7 +67,9 @@ int mbrl_step(const mbrl_model *m, int64_t N, const double *qpos, const double *
  *   dsda [N,n,nu]                                                            (backward.py:475 "action")
  *   drds [N,n], drda [N,nu]                                                  (backward.py:478)
  *   s_next [N,n], reward [N]: the nominal rollout (the `test=True` re-step, backward.py:362-374)
- * Any output pointer may be NULL. */
+ * Any output pointer may be NULL, status included: the results do not depend on which outputs are asked for (without
+ * a status array a HalfCheetah launch re-runs units with more than eight floor contacts inside the rollout kernel
+ * instead of in a fix-up launch; same bits, ~2 % slower). */
 int mbrl_fd_jacobians(const mbrl_model *m, int64_t N, const double *qpos, const double *qvel,
                       const double *ctrl, double eps, int fd_mode, int nsteps, double *dsds, double *dsda,
                       double *drds, double *drda, double *s_next, double *reward, uint32_t *status,
@@ -133,9 +137,13 @@ int mbrl_fd_plan_finish(const mbrl_model *m, int64_t plan_units, const double *r
  * address is looked up once per device in mbrl_model_create.  Inputs and outputs are the caller's, exactly as in
  * mbrl_fd_jacobians, and so are the results, bit for bit.  The call itself allocates nothing (no hipMalloc / hipFree,
  * no allocating library routine).  N > MBRL_STATIC_MAX_UNITS (or a plan beyond the array) is rejected with -8.
- * Every call on a GPU uses that GPU's one array: calls that overlap on one GPU (two streams, two threads) RACE --
- * serialise them, or use the caller-owned plan buffers of mbrl_fd_plan.  Nothing in the array needs clearing between
- * calls (each call rewrites the header, keys, order and nominal results of its own N units before reading them). */
+ * Every call on a GPU uses that GPU's one array: calls that overlap on one GPU (two streams, two threads) would RACE
+ * on it -- serialise them, or use the caller-owned plan buffers of mbrl_fd_plan.  An overlap is detected on the device
+ * (an in-flight counter in the array's header, bumped by the call's first launch and dropped by its last): every unit
+ * of a call that ran while another was in flight gets MBRL_ST_BADPLAN in its status word instead of silently wrong
+ * Jacobians (conservatively: also a call that started just before the other's last launch retired; with status == NULL
+ * the overlap goes unreported).  Nothing else in the array needs clearing between calls (each call rewrites the header,
+ * keys, order and nominal results of its own N units before reading them; the counter returns to zero). */
 #define MBRL_STATIC_MAX_UNITS 32768
 #define MBRL_STATIC_SCRATCH_BYTES (8u << 20)
 int mbrl_fd_jacobians_static(const mbrl_model *m, int64_t N, const double *qpos, const double *qvel, const double *ctrl,

@@ -216,12 +216,20 @@ class Agent:
                                             nsteps=int(cfg.MODEL.NSTEPS_FOR_BACKWARD),
                                             # backward.py:418-419,460-461: closed-loop re-query of the policy
                                             policy=agent.policy_net if cfg.MODEL.POLICY.NETWORK else None)
-            if test and int(cfg.MODEL.NSTEPS_FOR_BACKWARD) == 1:
-                ns = torch.as_tensor(next_state, device=out["s_next"].device).reshape(out["s_next"].shape)
-                rw = torch.as_tensor(reward, device=out["reward"].device).reshape(out["reward"].shape)
-                assert torch.equal(rw, out["reward"]), \
+            if test:
+                # backward.py:362-374: ONE env step from the snapshot must reproduce the forward pass exactly, whatever
+                # NSTEPS_FOR_BACKWARD is.  With one step per FD rollout that re-step is the linearisation's own nominal
+                # rollout; with more, its nominal covers nsteps env steps, so the single step is launched on its own.
+                if int(cfg.MODEL.NSTEPS_FOR_BACKWARD) == 1:
+                    s1, r1 = out["s_next"], out["reward"]
+                else:
+                    q1, v1, r1, _ = agent.engine.step(data_snapshot.qpos, data_snapshot.qvel, data_snapshot.ctrl)
+                    s1 = torch.cat([q1, v1], dim=-1)
+                ns = torch.as_tensor(next_state, device=s1.device).reshape(s1.shape)
+                rw = torch.as_tensor(reward, device=r1.device).reshape(r1.shape)
+                assert torch.equal(rw, r1), \
                     "reward is different from forward pass at timepoint {}".format(data_snapshot.time)
-                assert torch.equal(ns, out["s_next"]), "state is different from forward pass"
+                assert torch.equal(ns, s1), "state is different from forward pass"
             sq = (lambda t: t[0]) if agent.batch == 1 else (lambda t: t)
             agent.dynamics_gradients = {"state": sq(out["dsds"]), "action": sq(out["dsda"])}
             agent.reward_gradients = {"state": sq(out["drds"].unsqueeze(-2)), "action": sq(out["drda"].unsqueeze(-2))}

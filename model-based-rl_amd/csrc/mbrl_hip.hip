@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <new>
 
@@ -257,7 +258,7 @@ __device__ __forceinline__ void wave_outputs(const double *o, const int t, const
 #else
 #define MBRL_KERNEL_ATTR
 #endif
-constexpr int MODE_MASK = 3, MODE_NO_REDO = 8;   // mode argument: MODE_* | flags
+constexpr int MODE_MASK = 3, MODE_NO_REDO = 8, MODE_FORCE_WIDE = 16;   // mode argument: MODE_* | flags (debug: mbrl_debug_set_flags)
 // Units with more floor contacts than the 8 slots of the fast rollouts are re-run with one slot per floor candidate:
 // either by the wave that found them, right away, or by a fix-up launch afterwards (overflow_kernel).  Measured
 // (profiles/r02_experiments.md):
@@ -267,9 +268,12 @@ constexpr int MODE_MASK = 3, MODE_NO_REDO = 8;   // mode argument: MODE_* | flag
 //   * HalfCheetah: in the wave for step / plan launches (STEP_NAME kernels: no extra launch after each of a rollout's
 //     40 step launches, 1 ms per training epoch), a fix-up launch after the FD launches (never needed on trajectories;
 //     the wide code inside the FD kernel cost the pipelined bench 1.7 %, the fix-up launch costs it 0.2 %).
-template <class M, bool STEP_NAME> constexpr bool kRedoInWave = M::ENV_ID == 4 || STEP_NAME;
+//   * FD launches WITHOUT a status array (the ABI allows status == NULL) have nothing a fix-up launch could scan: they run
+//     a third instantiation of the kernel, REDO_FD, that re-runs in the wave like Walker2d's.  Only callers that pass no
+//     status pay its 1.7 %.
+template <class M, bool STEP_NAME, bool REDO_FD = false> constexpr bool kRedoInWave = M::ENV_ID == 4 || STEP_NAME || REDO_FD;
 template <class M> constexpr bool kNeedsRedo = (Layout<M>::NCAND > Layout<M>::K);
-template <class M, bool STEP_NAME>
+template <class M, bool STEP_NAME, bool REDO_FD = false>
 __global__ __launch_bounds__(kBlock) MBRL_KERNEL_ATTR void rollout_kernel(int64_t N, int frame_skip, int nsteps, double eps, int mode_arg,
                                                           const double *__restrict__ qpos,
                                                           const double *__restrict__ qvel,
@@ -345,12 +349,17 @@ __global__ __launch_bounds__(kBlock) MBRL_KERNEL_ATTR void rollout_kernel(int64_
     // ---- more than eight floor contacts at once (a walker lying flat): the rollout above dropped rows and flagged
     // itself MBRL_ST_OVERFLOW.  Re-run, in this very wave, every lane of a unit that has such a lane here, with one
     // contact slot per floor candidate (64-bit row masks).  The wider column is strided for 32 lanes so that it fits
-    // the LDS this workgroup already owns: lanes 0-31 first, then lanes 32-63.  Columns are differenced against a
-    // nominal of the same wave, hence of the same kind; a planned launch's nominal comes from the plan, whose own launch
-    // did the same.  Costs the wave a second (slower) set of rollouts -- planned launches start such units first (they
-    // carry the largest keys), so it hides under the rest of the launch; callers never see the flag.
-    if constexpr (kNeedsRedo<M> && kRedoInWave<M, STEP_NAME>) {
-        unsigned long long need = __builtin_amdgcn_ballot_w64(live && (st & ST_OVERFLOW));
+    // the LDS this workgroup already owns: lanes 0-31 first, then lanes 32-63.  A column may be differenced against a
+    // nominal of the OTHER kind (a planned launch's nominal comes from the plan, which stays 8-slot when the nominal
+    // itself did not overflow; a unit split over two waves can mix wide and narrow lanes): that is sound because the wide
+    // and the fast instantiation compute the same bits whenever at most eight contacts are active -- same operations in
+    // the same order, only the LDS addressing and the mask width differ -- which tests/test_gpu_overflow.py pins with
+    // MODE_FORCE_WIDE on units that do not overflow.  Costs the wave a second (slower) set of rollouts -- planned
+    // launches start such units first (they carry the largest keys), so it hides under the rest of the launch; callers
+    // never see the flag.
+    if constexpr (kNeedsRedo<M> && kRedoInWave<M, STEP_NAME, REDO_FD>) {
+        // (MODE_FORCE_WIDE, tests only: every unit takes the wide path, to pin that it computes the fast path's bits)
+        unsigned long long need = __builtin_amdgcn_ballot_w64(live && ((st & ST_OVERFLOW) || (mode_arg & MODE_FORCE_WIDE)));
         if (MBRL_RARE(need != 0 && !(mode_arg & MODE_NO_REDO))) {
             constexpr int KALL = 32, LANES = 32;                  // Layout clamps KALL to the number of floor candidates
             static_assert(Layout<M, KALL>::NMEM * LANES <= LY::NMEM * kBlock, "the wide columns must fit this workgroup's LDS");
@@ -412,13 +421,15 @@ __global__ __launch_bounds__(kBlock) void overflow_kernel(int64_t N, int frame_s
     constexpr int NV = M::NV, NS = 2 * NV, ROW = NS + 1, NP = M::NU + 2 * NV;
     static_assert(LY::NMEM * LANES <= Layout<M>::NMEM * kBlock, "the fix-up workgroup must fit wherever a fast-kernel wave fits");
     __shared__ double lds[LY::NMEM * LANES];
+    const bool force = (mode & MODE_FORCE_WIDE) != 0;                   // tests only: redo every unit
+    mode &= MODE_MASK;
     const bool central = mode == MODE_CENTRAL;
     const int P = mode == MODE_STEP ? 0 : (central ? 2 * NP : NP);      // perturbed rollouts per unit
     const int cap = central ? LANES - 2 : LANES - 1;                    // ... per chunk (couples stay whole)
     const int t = threadIdx.x;
     for (int64_t base = int64_t(blockIdx.x) * kBlock; base < N; base += int64_t(gridDim.x) * kBlock) {
         const unsigned s = base + t < N ? status[base + t] : 0u;
-        unsigned long long pend = __builtin_amdgcn_ballot_w64((s & ST_OVERFLOW) != 0u);
+        unsigned long long pend = __builtin_amdgcn_ballot_w64((s & ST_OVERFLOW) != 0u || (force && base + t < N));
         while (pend) {                             // wave-uniform: every lane sees the same ballot
             const int l = __builtin_ctzll(pend);
             pend &= pend - 1;
@@ -460,10 +471,39 @@ __global__ __launch_bounds__(kBlock) void overflow_kernel(int64_t N, int frame_s
     }
 }
 
+// Stream probe (mbrl_stream_probe_spin): single-wave workgroups that spin for `ticks` of the 100 MHz real-time counter.
+// Launched with a large dynamic LDS size, only a couple fit a CU, so a grid of a few thousand keeps the queue's
+// dispatcher busy for many rounds -- like the rollout kernels do -- and a launch queued BEHIND it on the same hardware
+// queue starts only when the last round has been placed.  Every wave leaves after `ticks` or 2^20 polls, whichever is first.
+__global__ __launch_bounds__(64) void spin_kernel(unsigned long long ticks) {
+    extern __shared__ unsigned char spin_pad[];
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (int guard = 0; guard < (1 << 20) && __builtin_amdgcn_s_memrealtime() - t0 < ticks; guard++) __builtin_amdgcn_s_sleep(16);
+    if (ticks == ~0ull) spin_pad[threadIdx.x] = 0;     // (keeps the allocation; never true for a real probe)
+}
+
 // status words start from zero (the rollout waves OR into them)
 __global__ __launch_bounds__(256) void zero_words_kernel(uint32_t *__restrict__ w, int64_t n) {
     const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (i < n) w[i] = 0u;
+}
+
+// ---- mbrl_fd_jacobians_static: overlapping calls on one GPU share that GPU's one plan array and would race on it.
+// Two control words in the (otherwise unused) tail of the plan header detect that on the device: ctl[0] counts the calls
+// in flight, ctl[1] is raised by a call that starts while another is in flight and stays up until the last one leaves.
+// Every call ends with static_flag_kernel -- if the word is up, its results cannot be trusted and every unit's status
+// gets MBRL_ST_BADPLAN -- and static_release_kernel.  Conservative: a call that starts in the short window between
+// another call's last rollout and its release is flagged although nothing was overwritten.
+constexpr size_t kStaticCtlOffset = 64;      // bytes into the plan header (PlanHeader uses 32 of its 256)
+__global__ void static_acquire_kernel(unsigned *ctl) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && atomicAdd(&ctl[0], 1u) != 0u) atomicExch(&ctl[1], 1u);
+}
+__global__ __launch_bounds__(256) void static_flag_kernel(unsigned *ctl, uint32_t *__restrict__ status, int64_t n) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n && __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) atomicOr(&status[i], ST_BADPLAN);
+}
+__global__ void static_release_kernel(unsigned *ctl) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && atomicSub(&ctl[0], 1u) == 1u) atomicExch(&ctl[1], 0u);
 }
 
 // mbrl_fd_plan_finish: header and identity order of a plan whose keys and nominal results were recorded by step launches.
@@ -537,6 +577,9 @@ struct mbrl_model {
 };
 
 static thread_local char g_err[512] = "";
+// Test knobs (mbrl_debug_set_flags, below; not part of include/mbrl.h): MODE_NO_REDO shows the flags the 8-slot rollouts
+// raise, MODE_FORCE_WIDE sends every unit through the wide re-run.  Zero in production; read once per launch.
+static std::atomic<int> g_debug_flags{0};
 static int fail(int code, const char *fmt, const char *a = "", long long b = 0) {
     snprintf(g_err, sizeof g_err, fmt, a, b);
     return code;
@@ -615,13 +658,19 @@ static int launch_rollouts(const mbrl_model *m, int64_t N, int mode, const doubl
     // the second replay on -- ROCm 7.2; tests/test_zz_no_alloc.py replays mbrl_fd_jacobians_static three times)
     if (status && !planned)
         hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, status, N);
-    // (MBRL_NO_OVERFLOW_REDO in the environment: tests use it to see the flags the 8-slot rollouts raise)
-    const int mode_arg = mode | (getenv("MBRL_NO_OVERFLOW_REDO") ? MODE_NO_REDO : 0);
+    const int mode_arg = mode | g_debug_flags.load(std::memory_order_relaxed);
     if (mode == MODE_STEP)
         hipLaunchKernelGGL((rollout_kernel<M, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, N, m->frame_skip, nsteps,
                            eps, mode_arg, qpos, qvel, ctrl, ctrl_pert, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward,
                            status, plan, plan_mode);
-    else
+    else if (kNeedsRedo<M> && !kRedoInWave<M, false> && !status) {
+        // no status array, so no fix-up launch: the instantiation that re-runs units with more than eight floor
+        // contacts in the wave (same results; include/mbrl.h "Any output pointer may be NULL")
+        if constexpr (kNeedsRedo<M> && !kRedoInWave<M, false>)
+            hipLaunchKernelGGL((rollout_kernel<M, false, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, N, m->frame_skip,
+                               nsteps, eps, mode_arg, qpos, qvel, ctrl, ctrl_pert, dsds, dsda, drds, drda, s_next, qpos_next,
+                               qvel_next, reward, status, plan, plan_mode);
+    } else
         hipLaunchKernelGGL((rollout_kernel<M, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, N, m->frame_skip, nsteps,
                            eps, mode_arg, qpos, qvel, ctrl, ctrl_pert, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward,
                            status, plan, plan_mode);
@@ -632,21 +681,36 @@ static int launch_rollouts(const mbrl_model *m, int64_t N, int mode, const doubl
         if (status && !(mode_arg & MODE_NO_REDO)) {
             int64_t fb = (N + kBlock - 1) / kBlock;
             if (fb > 1024) fb = 1024;
-            hipLaunchKernelGGL((overflow_kernel<M>), dim3((unsigned)fb), dim3(kBlock), 0, st, N, m->frame_skip, nsteps, eps, mode,
-                               qpos, qvel, ctrl, ctrl_pert, dsds, dsda, drds, drda, s_next, qpos_next, qvel_next, reward, status,
-                               planned ? nullptr : plan, planned ? PLAN_NONE : plan_mode);
+            hipLaunchKernelGGL((overflow_kernel<M>), dim3((unsigned)fb), dim3(kBlock), 0, st, N, m->frame_skip, nsteps, eps,
+                               mode | (mode_arg & MODE_FORCE_WIDE), qpos, qvel, ctrl, ctrl_pert, dsds, dsda, drds, drda, s_next,
+                               qpos_next, qvel_next, reward, status, planned ? nullptr : plan, planned ? PLAN_NONE : plan_mode);
         }
     }
     return 0;
 }
 
-static bool plan_layout(int64_t N, int ns, hipStream_t st, PlanLayout &L) {
-    L.sort_tmp = PlanOffsets(N, ns).end;
-    L.sort_bytes = 0;
+// Size of rocprim's sort scratch for n units: a host-side query (no launch) whose answer depends on n only, so it is
+// asked once per n and remembered -- mbrl_step_record / _planned / _finish sit in the latency-bound rollout loop.
+static bool sort_scratch_bytes(int64_t n, size_t &bytes) {
+    struct Entry { int64_t n; size_t bytes; };
+    static thread_local Entry cache[8] = {};
+    static thread_local int next = 0;
+    for (const Entry &e : cache)
+        if (e.n == n && e.bytes) { bytes = e.bytes; return true; }
+    bytes = 0;
     uint32_t *nil = nullptr;
     uint64_t *nil64 = nullptr;
-    if (rocprim::radix_sort_pairs(nullptr, L.sort_bytes, nil64, nil64, nil, nil, size_t(N), 0, kKeyBits, st) != hipSuccess)
+    if (rocprim::radix_sort_pairs(nullptr, bytes, nil64, nil64, nil, nil, size_t(n), 0, kKeyBits, hipStream_t(nullptr)) != hipSuccess)
         return false;
+    if (bytes == 0) bytes = 1;    // (never returned by rocprim for n > 0; keeps "0 = empty slot" unambiguous)
+    cache[next] = Entry{n, bytes};
+    next = (next + 1) % 8;
+    return true;
+}
+
+static bool plan_layout(int64_t N, int ns, hipStream_t, PlanLayout &L) {
+    L.sort_tmp = PlanOffsets(N, ns).end;
+    if (!sort_scratch_bytes(N, L.sort_bytes)) return false;
     L.total = (L.sort_tmp + L.sort_bytes + 255) & ~size_t(255);
     return true;
 }
@@ -658,6 +722,27 @@ extern "C" int mbrl_debug_phase_read(unsigned long long *host16, int reset) {
     return rc;
 }
 #endif
+
+// Utility for the host wrapper (engine.py picks a side stream that is SEEN to overlap the caller's stream; HIP has no query
+// for which hardware queue a stream uses): `blocks` single-wave workgroups with lds_bytes of LDS each spin for `usec`
+// microseconds on hip_stream.  Not part of include/mbrl.h.
+extern "C" int mbrl_stream_probe_spin(const mbrl_model *m, int blocks, int usec, int lds_bytes, void *hip_stream) {
+    if (!m) return fail(-1, "mbrl_stream_probe_spin: null model");
+    if (blocks < 1 || blocks > (1 << 16) || usec < 1 || usec > 20000 || lds_bytes < 0 || lds_bytes > 64 * 1024)
+        return fail(-7, "mbrl_stream_probe_spin: argument out of range");
+    if (hipSetDevice(m->device) != hipSuccess) return fail(-4, "mbrl_stream_probe_spin: hipSetDevice failed");
+    hipLaunchKernelGGL(spin_kernel, dim3((unsigned)blocks), dim3(64), (size_t)lds_bytes, (hipStream_t)hip_stream,
+                       (unsigned long long)usec * 100ull);
+    return check_launch(m, "mbrl_stream_probe_spin");
+}
+
+// Test knob, deliberately outside include/mbrl.h: bit 0 = no re-run of units with more than eight floor contacts (their
+// MBRL_ST_OVERFLOW flag stays visible), bit 1 = every unit takes the wide re-run.  Returns the previous setting.
+extern "C" int mbrl_debug_set_flags(int flags) {
+    const int v = ((flags & 1) ? MODE_NO_REDO : 0) | ((flags & 2) ? MODE_FORCE_WIDE : 0);
+    const int old = g_debug_flags.exchange(v);
+    return ((old & MODE_NO_REDO) ? 1 : 0) | ((old & MODE_FORCE_WIDE) ? 2 : 0);
+}
 
 #ifdef MBRL_WAVE_TIMING
 extern "C" int mbrl_debug_set_wave_timing(void *buf) {
@@ -918,11 +1003,33 @@ int mbrl_fd_jacobians_static(const mbrl_model *m, int64_t N, const double *qpos,
     if (L.total > kStaticScratchBytes)
         return fail(-8, "mbrl_fd_jacobians_static: the plan of this batch does not fit the static scratch%s (%lld bytes)", "",
                     (long long)L.total);
-    // both launches take the device address looked up at set-up, never the symbol's name
+    // every launch takes the device address looked up at set-up, never the symbol's name
+    hipStream_t st = (hipStream_t)hip_stream;
+    unsigned *ctl = reinterpret_cast<unsigned *>(static_cast<char *>(ptr) + kStaticCtlOffset);
+    hipLaunchKernelGGL(static_acquire_kernel, dim3(1), dim3(64), 0, st, ctl);
     int rc = mbrl_fd_plan(m, N, qpos, qvel, ctrl, nsteps, ptr, int64_t(kStaticScratchBytes), s_next, reward, status, hip_stream);
+    if (!rc)
+        rc = mbrl_fd_jacobians_planned(m, N, qpos, qvel, ctrl, nullptr, eps, fd_mode, nsteps, ptr, int64_t(kStaticScratchBytes),
+                                       dsds, dsda, drds, drda, status, hip_stream);
+    // a call that overlapped another one on this GPU raced on the array: say so in the status words, then leave
+    if (!rc && status)
+        hipLaunchKernelGGL(static_flag_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, ctl, status, N);
+    hipLaunchKernelGGL(static_release_kernel, dim3(1), dim3(64), 0, st, ctl);
     if (rc) return rc;
-    return mbrl_fd_jacobians_planned(m, N, qpos, qvel, ctrl, nullptr, eps, fd_mode, nsteps, ptr, int64_t(kStaticScratchBytes),
-                                     dsds, dsda, drds, drda, status, hip_stream);
+    return check_launch(m, "mbrl_fd_jacobians_static");
+}
+
+// Test knob, outside include/mbrl.h: stands in for ANOTHER mbrl_fd_jacobians_static call in flight on the model's GPU
+// (enter = 1: as if it had started; 0: as if it had finished), so that the overlap detection can be tested without a race.
+int mbrl_debug_static_hold(const mbrl_model *m, int enter, void *hip_stream) {
+    if (!m) return fail(-1, "mbrl_debug_static_hold: null model");
+    void *ptr = (m->device >= 0 && m->device < kMaxDevices) ? g_scratch_ptr[m->device] : nullptr;
+    if (!ptr) return fail(-10, "mbrl_debug_static_hold: no static scratch on this device");
+    if (hipSetDevice(m->device) != hipSuccess) return fail(-4, "mbrl_debug_static_hold: hipSetDevice failed");
+    unsigned *ctl = reinterpret_cast<unsigned *>(static_cast<char *>(ptr) + kStaticCtlOffset);
+    if (enter) hipLaunchKernelGGL(static_acquire_kernel, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, ctl);
+    else hipLaunchKernelGGL(static_release_kernel, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, ctl);
+    return check_launch(m, "mbrl_debug_static_hold");
 }
 
 int mbrl_vjp_scan(const mbrl_model *m, int64_t B, int H, int grad_weights, const double *dsds, const double *dsda,

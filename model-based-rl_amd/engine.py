@@ -15,6 +15,48 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+def _runs_beside(engine, main, cand):
+    """Does work on stream `cand` actually run WHILE a long launch on `main` is in flight?  Two HIP streams of one process
+    can share a hardware queue (GPU_MAX_HW_QUEUES is 4 on the box, and everything that creates streams -- torch's pools,
+    an RCCL communicator -- takes slots).  A queue hands its packets to the dispatcher in order, and a grid that is much
+    larger than the chip holds its queue until its last workgroup has been placed: a launch queued behind it on the same
+    queue starts when the big one is all but finished, whatever stream it came from.  HIP has no query for the mapping,
+    so it is measured: a spin grid of 4 096 workgroups (two fit a CU: eight rounds of 50 us) on `main`, one short
+    workgroup on `cand`; side by side they take the big grid's time, in one queue the sum."""
+    L, h = engine.L, engine.h
+    sm, sc = C.c_void_p(main.cuda_stream), C.c_void_p(cand.cuda_stream)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    big = lambda: lib.check(L.mbrl_stream_probe_spin(h, 4096, 50, 60 * 1024, sm))
+    big()                                                    # warm-up (code load)
+    lib.check(L.mbrl_stream_probe_spin(h, 1, 10, 0, sc))
+    main.synchronize(); cand.synchronize()
+    ev[0].record(main); big(); ev[1].record(main)
+    ev[1].synchronize()
+    alone = ev[0].elapsed_time(ev[1])
+    ev[0].record(main)
+    big()
+    lib.check(L.mbrl_stream_probe_spin(h, 1, 200, 0, sc))    # 0.2 ms, queued while the big grid is being placed
+    main.wait_stream(cand)
+    ev[2].record(main)
+    ev[2].synchronize()
+    return ev[0].elapsed_time(ev[2]) < alone + 0.1
+
+
+def concurrent_stream(engine, tries=8):
+    """A stream of the engine's device that overlaps with the CURRENT stream (see _runs_beside).  Candidates that share
+    the current stream's hardware queue are kept alive while the next one is tried (so the runtime hands out another
+    slot) and dropped afterwards.  Falls back to the first candidate -- correct, only without the overlap -- when none
+    passes.  Returns (stream, number of candidates rejected or -1)."""
+    main = torch.cuda.current_stream(engine.device)
+    rejected = []
+    for _ in range(tries):
+        s = torch.cuda.Stream(device=engine.device)
+        if _runs_beside(engine, main, s):
+            return s, len(rejected)
+        rejected.append(s)
+    return rejected[0], -1
+
+
 class Plan:
     """Launch-plan workspace of the two-launch linearisation (include/mbrl.h: mbrl_fd_plan): a grow-only device buffer
     and the batch size its current plan was made for."""
@@ -75,7 +117,12 @@ class FdEngine:
         high-priority stream gained the bench 0.3 %, and with the linearisation on one a training run stopped making
         progress -- not worth it."""
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            # not just any new stream: one that is seen to run beside the caller's.  (Found with MBRL_FORCE_DIST=1: once
+            # an RCCL communicator exists, the next stream torch hands out shares the default stream's hardware queue,
+            # the plan launch no longer overlapped the perturbed rollouts and the bench lost 3 % -- on every rank of a
+            # multi-GPU run.)  side_stream_rejected: candidates that were seen to serialise, -1: none overlapped.
+            with torch.cuda.device(self.device):
+                self._side, self.side_stream_rejected = concurrent_stream(self)
         return self._side
 
     def _new(self, *shape, dtype=torch.float64):

@@ -58,7 +58,11 @@ def load():
     L.mbrl_vjp_scan_sharded.argtypes = [vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64] + [vp] * 7 + [vp]
     L.mbrl_step_record.argtypes = [vp, C.c_int64] + [vp] * 7 + [vp, C.c_int64, C.c_int64, C.c_int64, vp]
     L.mbrl_fd_plan_finish.argtypes = [vp, C.c_int64, vp, vp, C.c_int64, vp]
-    if L.mbrl_abi_version() != 7:
+    # test knobs outside include/mbrl.h (tests/test_gpu_overflow.py, tests/test_zz_no_alloc.py)
+    L.mbrl_debug_set_flags.argtypes = [C.c_int]
+    L.mbrl_debug_static_hold.argtypes = [vp, C.c_int, vp]
+    L.mbrl_stream_probe_spin.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]     # engine.py: side-stream selection
+    if L.mbrl_abi_version() != 8:
         raise MbrlError("ABI version mismatch")
     _lib = L
     return L

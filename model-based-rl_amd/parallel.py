@@ -19,9 +19,15 @@ def shard_range(n, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def active():
+    """A process group exists -- also one of a single rank (MBRL_FORCE_DIST=1 runs the collectives of the multi-GPU path
+    on a one-GPU box; summing over one rank changes no bit)."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def allreduce_sum_(tensors):
     """In-place sum over ranks of a list of tensors with ONE collective (flatten -> all_reduce -> unflatten)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not active():
         return tensors
     flat = torch.cat([t.reshape(-1) for t in tensors])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
@@ -35,7 +41,7 @@ def allreduce_sum_(tensors):
 
 def max_over_ranks(x):
     """Max of a python float over ranks (bench timing)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not active():
         return float(x)
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     t = torch.tensor([float(x)], dtype=torch.float64, device=dev)

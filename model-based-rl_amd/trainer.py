@@ -63,8 +63,9 @@ def build_model(cfg, agent, shard=None):
 def do_training(cfg, logger, output_results_dir, output_rec_dir, output_weights_dir, iter, device=None, engine=None):
     """`engine`: an object with FdEngine's interface to use instead of creating one on `device` (the world-size-2 CPU
     test passes a stand-in; the product path always creates the HIP engine)."""
-    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
-    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    grouped = parallel.active()            # a process group exists (possibly of one rank: MBRL_FORCE_DIST)
+    rank = dist.get_rank() if grouped else 0
+    world = dist.get_world_size() if grouped else 1
     if cfg.MODEL.RANDOM_SEED > 0:                                   # trainer.py:21-23
         np.random.seed(cfg.MODEL.RANDOM_SEED + iter)
         torch.manual_seed(cfg.MODEL.RANDOM_SEED + iter)
@@ -114,8 +115,8 @@ def do_training(cfg, logger, output_results_dir, output_rec_dir, output_weights_
                     logger.warning("epoch %d: %d of %d episodes masked from their first flagged step (status bits, "
                                    "include/mbrl.h)" % (epoch_idx, int(dead.any(dim=1).sum()), hi - lo))
         agent.running_sum = 0                                       # trainer.py:76
-        loss = policy.optimize(batch_loss, grad_sync=grad_sync if world > 1 else None)   # trainer.py:77
-        if world > 1:   # logged objective = batch mean of episode losses over ALL ranks' episodes
+        loss = policy.optimize(batch_loss, grad_sync=grad_sync if grouped else None)   # trainer.py:77
+        if grouped:     # logged objective = batch mean of episode losses over ALL ranks' episodes
             t = torch.tensor([loss["objective_loss"] * (hi - lo)], dtype=torch.float64, device=eng.device)
             dist.all_reduce(t)
             loss["objective_loss"] = float(t.item()) / B

@@ -1208,9 +1208,9 @@ static double rollout(const Model *m, Data *d, const double *qpos, const double 
     return r;
 }
 
-int mjo_fd_jacobians(int id, int frame_skip, int64_t N, const double *qpos, const double *qvel, const double *ctrl,
-                     double eps, int fd_mode, int nsteps, double *dsds, double *dsda, double *drds, double *drda,
-                     double *s_next, double *reward, uint32_t *status, int nthreads) {
+static int fd_impl(int id, int frame_skip, int64_t N, const double *qpos, const double *qvel, const double *ctrl,
+                   double eps, int fd_mode, int nsteps, double *dsds, double *dsda, double *drds, double *drda,
+                   double *s_next, double *reward, uint32_t *status, int32_t *evals_constrained, int nthreads) {
     Model *m = get_model(id);
     if (!m) return -1;
     if (frame_skip <= 0) frame_skip = m->frame_skip;
@@ -1243,9 +1243,27 @@ int mjo_fd_jacobians(int id, int frame_skip, int64_t N, const double *qpos, cons
             }
         }
         if (status) status[i] = d.status;
+        if (evals_constrained) evals_constrained[i] = (int32_t)d.n_eval_con;
         if (nthreads <= 1) { g_n_eval += d.n_eval; g_n_eval_con += d.n_eval_con; g_sum_iter += d.sum_iter; g_sum_nefc += d.sum_nefc; }
     }
     return 0;
+}
+
+int mjo_fd_jacobians(int id, int frame_skip, int64_t N, const double *qpos, const double *qvel, const double *ctrl,
+                     double eps, int fd_mode, int nsteps, double *dsds, double *dsda, double *drds, double *drda,
+                     double *s_next, double *reward, uint32_t *status, int nthreads) {
+    return fd_impl(id, frame_skip, N, qpos, qvel, ctrl, eps, fd_mode, nsteps, dsds, dsda, drds, drda, s_next, reward, status,
+                   NULL, nthreads);
+}
+
+/* The same, also reporting per unit how many dynamics evaluations of its rollouts (nominal and perturbed) had at least
+ * one active constraint row -- joint limit or contact.  The full-size parity tests use it to tell the contact-rich units,
+ * for which the FD tolerance is stated separately, from the smooth ones. */
+int mjo_fd_jacobians_info(int id, int frame_skip, int64_t N, const double *qpos, const double *qvel, const double *ctrl,
+                          double eps, int fd_mode, int nsteps, double *dsds, double *dsda, double *drds, double *drda,
+                          double *s_next, double *reward, uint32_t *status, int32_t *evals_constrained, int nthreads) {
+    return fd_impl(id, frame_skip, N, qpos, qvel, ctrl, eps, fd_mode, nsteps, dsds, dsda, drds, drda, s_next, reward, status,
+                   evals_constrained, nthreads);
 }
 
 int mjo_stats(double *mean_newton_iters, double *frac_evals_constrained, double *mean_nefc) {

@@ -2,7 +2,7 @@
 fast kernel flags such units MBRL_ST_OVERFLOW; the fix-up launch that follows every rollout launch re-runs them with one
 contact slot per floor candidate, so the caller sees no flag and results that agree with the oracle (24 contacts) like
 any other unit's."""
-import os
+import ctypes as C
 
 import numpy as np
 import pytest
@@ -43,11 +43,11 @@ def test_units_with_more_than_eight_contacts_are_fixed_up(env):
     N = 96
     q, v, c = flat_states(env, N, 3)
     # the states do overflow the fast kernel (seen with the fix-up switched off) ...
-    os.environ["MBRL_NO_OVERFLOW_REDO"] = "1"
+    e.L.mbrl_debug_set_flags(1)          # test knob outside include/mbrl.h: no re-run, the raw flags stay visible
     try:
         raw = e.step(q, v, c)[3].cpu().numpy()
     finally:
-        del os.environ["MBRL_NO_OVERFLOW_REDO"]
+        e.L.mbrl_debug_set_flags(0)
     assert ((raw & 4) != 0).sum() >= N // 8, int(((raw & 4) != 0).sum())
     # ... and the caller never sees it: env.step
     qo, vo, ro, so = o.step(q, v, c, nthreads=8)
@@ -101,3 +101,106 @@ def test_recorded_plan_of_overflowing_units():
     torch.cuda.synchronize()
     for k in ("dsds", "dsda", "drds", "drda", "status"):
         assert torch.equal(ref[k], out[k]), k
+
+
+NAMES = ("dsds", "dsda", "drds", "drda", "s_next", "reward", "status")
+
+
+def _fd(e, q, v, c, fd_mode, o, with_status=True):
+    """mbrl_fd_jacobians through the C ABI; with_status=False passes status = NULL."""
+    import torch
+    p = lambda t: C.c_void_p(t.data_ptr())
+    ptrs = [p(o[k]) for k in NAMES]
+    if not with_status:
+        ptrs[-1] = C.c_void_p(0)
+    rc = e.L.mbrl_fd_jacobians(e.h, q.shape[0], p(q), p(v), p(c), 1e-6, fd_mode, 1, *ptrs,
+                               C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, e.L.mbrl_last_error()
+
+
+@pytest.mark.parametrize("env", ["Walker2dEnv", "HalfCheetahEnv"])
+def test_wide_rerun_computes_the_fast_paths_bits_on_units_that_do_not_overflow(env):
+    """The re-run with one contact slot per floor candidate (lane_rollout<M, 32, 32>: wider LDS column strided for 32
+    lanes, 64-bit row masks) and the fast rollouts (lane_rollout<M, 8, 64>) are different template instantiations, and a
+    perturbed lane that is re-run wide may be differenced against a nominal that was not (planned launches; units split
+    over two waves).  That is sound only if the two compute the SAME BITS whenever at most eight contacts are active.
+    Pinned here: with the debug flag that sends EVERY unit through the wide path (in the wave for Walker2d and for
+    HalfCheetah's step / plan / status-less FD launches, by the fix-up launch after HalfCheetah's FD launches), ordinary
+    on-trajectory units give the bits of the normal path on every output of every entry point."""
+    import torch
+    import mbrl_amd  # noqa: F401
+    from mbrl_amd import workloads
+    from mbrl_amd.engine import FdEngine
+    e = FdEngine(env)
+    N = 700
+    q, v, c = workloads.s2(e, N, seed=11, horizon=40)
+    step0 = e.step(q, v, c)
+    fd0 = {(m, pl): e.fd_jacobians(q, v, c, fd_mode=m, planned=pl) for m in (0, 1) for pl in (False, True)}
+    nost0 = e.new_outputs(N)
+    _fd(e, q, v, c, 0, nost0, with_status=False)
+    torch.cuda.synchronize()
+    assert int(step0[3].abs().sum()) == 0
+    e.L.mbrl_debug_set_flags(2)
+    try:
+        step1 = e.step(q, v, c)
+        fd1 = {(m, pl): e.fd_jacobians(q, v, c, fd_mode=m, planned=pl) for m in (0, 1) for pl in (False, True)}
+        nost1 = e.new_outputs(N)
+        _fd(e, q, v, c, 0, nost1, with_status=False)
+        torch.cuda.synchronize()
+    finally:
+        e.L.mbrl_debug_set_flags(0)
+    for a, b in zip(step0, step1):
+        assert torch.equal(a, b)
+    for key in fd0:
+        for k in NAMES:
+            assert torch.equal(fd0[key][k], fd1[key][k]), (key, k)
+    for k in NAMES[:-1]:
+        assert torch.equal(nost0[k], nost1[k]) and torch.equal(nost0[k], fd0[(0, False)][k]), k
+
+
+def test_linearisation_without_a_status_array_is_the_one_with_it():
+    """include/mbrl.h: any output pointer may be NULL, status included.  HalfCheetah's FD launches normally hand units
+    with more than eight floor contacts to a fix-up launch that scans the status words; without a status array they
+    run the kernel instantiation that re-runs such units in the wave instead.  Flat-lying cheetahs (every unit
+    overflows) and on-trajectory ones: same bits either way, and equal to the oracle like any other unit."""
+    import torch
+    import mbrl_amd  # noqa: F401
+    from mbrl_amd import workloads
+    from mbrl_amd.engine import FdEngine
+    from oracle import Oracle
+    env = "HalfCheetahEnv"
+    e, o = FdEngine(env), Oracle(env)
+    N = 96
+    qf, vf, cf = (torch.as_tensor(x, device="cuda") for x in flat_states(env, N, 3))
+    qt, vt, ct = workloads.s2(e, N, seed=5, horizon=40)
+    q, v, c = torch.cat([qf, qt]), torch.cat([vf, vt]), torch.cat([cf, ct])
+    for fd_mode in (0, 1):
+        a, b = e.new_outputs(2 * N), e.new_outputs(2 * N)
+        for k in NAMES:
+            a[k].fill_(7); b[k].fill_(7)
+        _fd(e, q, v, c, fd_mode, a, with_status=True)
+        _fd(e, q, v, c, fd_mode, b, with_status=False)
+        torch.cuda.synchronize()
+        assert int(a["status"].abs().sum()) == 0 and bool((b["status"] == 7).all())      # b's array was never touched
+        for k in NAMES[:-1]:
+            assert torch.equal(a[k], b[k]), (k, fd_mode)
+        ref = o.fd_jacobians(q.cpu().numpy(), v.cpu().numpy(), c.cpu().numpy(), fd_mode=fd_mode, nthreads=8)
+        for k in ("dsds", "dsda", "drds", "drda"):
+            x, y = b[k].cpu().numpy().reshape(2 * N, -1), ref[k].reshape(2 * N, -1)
+            rel = np.abs(x - y).max(axis=1) / (1.0 + np.abs(y).max(axis=1))
+            assert rel.max() < (5e-6 if fd_mode == 0 else 2e-6), (k, fd_mode, float(rel.max()))
+    # the planned launch takes the same route when its status pointer is NULL
+    plan_out = e.fd_plan(q, v, c)
+    out = e.new_outputs(2 * N)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    pl = e._stream_plan()
+    rc = e.L.mbrl_fd_jacobians_planned(e.h, 2 * N, p(q), p(v), p(c), C.c_void_p(0), 1e-6, 0, 1, p(pl.buf), pl.buf.numel(),
+                                       p(out["dsds"]), p(out["dsda"]), p(out["drds"]), p(out["drda"]), C.c_void_p(0),
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, e.L.mbrl_last_error()
+    full = e.new_outputs(2 * N)
+    _fd(e, q, v, c, 0, full, with_status=True)
+    torch.cuda.synchronize()
+    for k in ("dsds", "dsda", "drds", "drda"):
+        assert torch.equal(out[k], full[k]), k
+    assert torch.equal(plan_out["s_next"], full["s_next"])

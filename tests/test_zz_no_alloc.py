@@ -102,3 +102,41 @@ def test_static_entry_point_replays_from_a_captured_hip_graph():
         torch.cuda.synchronize()
         for k in NAMES:
             assert torch.equal(ref[k], o[k]), k
+
+
+def test_static_calls_that_overlap_are_flagged_not_silently_wrong():
+    """Every static call on a GPU shares that GPU's one plan array, so calls that overlap would race on it.  The array's
+    header counts the calls in flight; a call that runs while another is in flight gets MBRL_ST_BADPLAN on every unit.
+    The other call is stood in for by the test knob mbrl_debug_static_hold (no real race needed): held -> flagged;
+    released -> the next call is clean again and bit-equal to mbrl_fd_jacobians."""
+    import torch
+    import mbrl_amd  # noqa: F401
+    from mbrl_amd import lib, workloads
+    from mbrl_amd.engine import FdEngine
+    e = FdEngine("HalfCheetahEnv")
+    N = 1500
+    q, v, c = workloads.s2(e, N, seed=4, horizon=8)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ref, got = e.new_outputs(N), e.new_outputs(N)
+    assert _call(e.L.mbrl_fd_jacobians, e, q, v, c, 0, 1, ref) == 0
+    assert e.L.mbrl_debug_static_hold(e.h, 1, st) == 0                 # "another call has started"
+    assert _call(e.L.mbrl_fd_jacobians_static, e, q, v, c, 0, 1, got) == 0
+    torch.cuda.synchronize()
+    assert bool(((got["status"] & lib.ST_BADPLAN) != 0).all())
+    assert e.L.mbrl_debug_static_hold(e.h, 0, st) == 0                 # "... and finished"
+    for k in NAMES:
+        got[k].fill_(7)
+    assert _call(e.L.mbrl_fd_jacobians_static, e, q, v, c, 0, 1, got) == 0
+    torch.cuda.synchronize()
+    for k in NAMES:
+        assert torch.equal(ref[k], got[k]), k
+    # two real calls on two streams, serialised by the caller with an event: clean
+    side = torch.cuda.Stream()
+    other = e.new_outputs(N)
+    assert _call(e.L.mbrl_fd_jacobians_static, e, q, v, c, 0, 1, got) == 0
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        assert _call(e.L.mbrl_fd_jacobians_static, e, q, v, c, 0, 1, other) == 0
+    torch.cuda.synchronize()
+    for k in NAMES:
+        assert torch.equal(ref[k], got[k]) and torch.equal(ref[k], other[k]), k
