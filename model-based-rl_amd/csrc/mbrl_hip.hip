@@ -28,14 +28,16 @@
 #ifdef MBRL_PHASE_TIMING   // profiling build only (tools/phase_timing.py): shader-clock totals per solver phase
 // Light marks: the previous stamp lives in a scalar register pair, the per-wave totals in LDS (fire-and-forget
 // ds_add); phase 10 is a back-to-back pair of marks, i.e. the cost of one mark, for calibration.
-__device__ unsigned long long g_phase_acc[16];
-__shared__ unsigned long long s_phase_acc[4][16];
+__device__ unsigned long long g_phase_acc[32];       // [0..15] shader clocks per phase, [16..31] times the phase was charged
+__shared__ unsigned long long s_phase_acc[4][32];
 __device__ __forceinline__ void mbrl_phase_mark(int k, unsigned long long &last) {
     const unsigned long long now = __builtin_amdgcn_s_memtime();
     const unsigned long long dt = now - last;
     last = now;
-    if (k != 15 && (threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
+    if (k != 15 && (threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) {
         atomicAdd(&s_phase_acc[threadIdx.x >> 6][k], dt);
+        atomicAdd(&s_phase_acc[threadIdx.x >> 6][16 + k], 1ull);
+    }
 }
 #define MBRL_PHASE(k) mbrl_phase_mark(k, mbrl_phase_last)
 #define MBRL_PHASE_MEMBER unsigned long long mbrl_phase_last;
@@ -175,7 +177,7 @@ __device__ __forceinline__ void lane_rollout(double *col, const int64_t unit, co
 #ifdef MBRL_PHASE_TIMING
     {
         unsigned long long &mbrl_phase_last = S.mbrl_phase_last;
-        for (int k = 0; k < 16; k++) s_phase_acc[threadIdx.x >> 6][k] = 0;
+        for (int k = 0; k < 32; k++) s_phase_acc[threadIdx.x >> 6][k] = 0;
         MBRL_PHASE(15);
         MBRL_PHASE(10);
     }
@@ -187,7 +189,7 @@ __device__ __forceinline__ void lane_rollout(double *col, const int64_t unit, co
         MBRL_PHASE(9);
         MBRL_PHASE(10);
         if ((threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
-            for (int k = 0; k < 16; k++) atomicAdd(&g_phase_acc[k], s_phase_acc[threadIdx.x >> 6][k]);
+            for (int k = 0; k < 32; k++) atomicAdd(&g_phase_acc[k], s_phase_acc[threadIdx.x >> 6][k]);
     }
 #endif
     S.check_finite();
@@ -585,14 +587,20 @@ static int fail(int code, const char *fmt, const char *a = "", long long b = 0) 
     return code;
 }
 
+// -DMBRL_ONLY_ENV=k (A/B and ISA-inspection builds): only model k is instantiated, the others report "unknown env"
+#ifdef MBRL_ONLY_ENV
+#define MBRL_CASE(k, MODEL, CALL) case k: if constexpr (k == MBRL_ONLY_ENV) { using M = MODEL; CALL; } break;
+#else
+#define MBRL_CASE(k, MODEL, CALL) case k: { using M = MODEL; CALL; } break;
+#endif
 #define MBRL_DISPATCH(id, CALL)                                        \
     switch (id) {                                                      \
-    case 0: { using M = MdlInvertedPendulum; CALL; } break;            \
-    case 1: { using M = MdlInvertedDoublePendulum; CALL; } break;      \
-    case 2: { using M = MdlSwimmer; CALL; } break;                     \
-    case 3: { using M = MdlHopper; CALL; } break;                      \
-    case 4: { using M = MdlWalker2d; CALL; } break;                    \
-    case 5: { using M = MdlHalfCheetah; CALL; } break;                 \
+    MBRL_CASE(0, MdlInvertedPendulum, CALL)                            \
+    MBRL_CASE(1, MdlInvertedDoublePendulum, CALL)                      \
+    MBRL_CASE(2, MdlSwimmer, CALL)                                     \
+    MBRL_CASE(3, MdlHopper, CALL)                                      \
+    MBRL_CASE(4, MdlWalker2d, CALL)                                    \
+    MBRL_CASE(5, MdlHalfCheetah, CALL)                                 \
     default: break;                                                    \
     }
 
@@ -716,9 +724,9 @@ static bool plan_layout(int64_t N, int ns, hipStream_t, PlanLayout &L) {
 }
 
 #ifdef MBRL_PHASE_TIMING
-extern "C" int mbrl_debug_phase_read(unsigned long long *host16, int reset) {
-    int rc = (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_phase_acc), sizeof(unsigned long long) * 16);
-    if (reset) { unsigned long long z[16] = {0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_acc), z, sizeof z); }
+extern "C" int mbrl_debug_phase_read(unsigned long long *host32, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(g_phase_acc), sizeof(unsigned long long) * 32);
+    if (reset) { unsigned long long z[32] = {0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_acc), z, sizeof z); }
     return rc;
 }
 #endif

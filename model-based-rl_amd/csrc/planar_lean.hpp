@@ -45,6 +45,9 @@
 // instruction buffer, which nothing hides at one wave per SIMD)
 #ifdef MBRL_NO_EXPECT
 #define MBRL_RARE(c) (c)
+#elif defined(MBRL_UNIFORM_RARE) && defined(__HIP_DEVICE_COMPILE__)
+// A/B: wave-uniform outer test (scalar branch, exec untouched on the fall-through path), divergent test only inside
+#define MBRL_RARE(c) (__builtin_expect(__builtin_amdgcn_ballot_w64(!!(c)) != 0, 0) && (c))
 #else
 #define MBRL_RARE(c) __builtin_expect(!!(c), 0)
 #endif
@@ -55,14 +58,30 @@
 #define MBRL_LOOP_FENCE asm volatile("" ::: "memory")
 #define MBRL_OPAQUE(x) asm volatile("" : "+v"(x))
 #define MBRL_WAVE_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0)   // true in every active lane if any active lane has c
+// Placed right after a row prefetch (Pop::next, which ends in a fence the loads cannot cross): everything computed from x
+// is ordered AFTER the loads, so they are issued at the top of the block and their latency runs under the block's own
+// arithmetic.  (Left to itself the scheduler sinks the loads to the bottom of the block, next to the copies into the
+// loop-carried row registers, and the wait for them is fully exposed -- once per active row and pass.)
+#ifdef MBRL_NO_ANCHOR
+#define MBRL_ANCHOR(x)
+#else
+#define MBRL_ANCHOR(x) asm volatile("" : "+v"(x))
+#endif
 #else
 #define MBRL_LOOP_FENCE
 #define MBRL_OPAQUE(x)
 #define MBRL_WAVE_ANY(c) (c)
+#define MBRL_ANCHOR(x)
 #endif
 
 // profiling builds only (tools/phase_timing.py): the kernel source defines MBRL_PHASE(k) to charge the shader clock
 // since the previous mark to phase k
+// -DMBRL_ASM_MARKS (ISA inspection only): named comment lines in the assembly at the phase boundaries
+#if defined(MBRL_ASM_MARKS) && defined(__HIP_DEVICE_COMPILE__)
+#define MBRL_MARK(name) asm volatile("; MBRL_MARK " name)
+#else
+#define MBRL_MARK(name)
+#endif
 #ifndef MBRL_PHASE
 #define MBRL_PHASE(k)
 #define MBRL_PHASE_MEMBER
@@ -320,6 +339,16 @@ struct Lean {
     T ha[NB], hb[NB], IO[NB];            // first moment m*(com - O) and inertia about O
     T fsm[NV], qacc[NV], fcon[NV];
     T site_a, site_b;
+    // Joint-space inertia  M + armature  (lower triangle, tree-sparse) of the CURRENT dynamics evaluation: built once by
+    // the composite-rigid-body pass and then shared by everything that needs it -- the unconstrained solve, every Newton
+    // Hessian (HM + explicit J^T D J of the few active rows), (M + arm) s of the line search, and Euler's implicit-damping
+    // factorisation (HM + h diag(damping)).  Before, each of those ran its own leaf-to-root pass over the body inertias.
+    T HM[NV][NV];
+#ifdef MBRL_NO_HM
+    static constexpr bool kHM = false;      // A/B: round-2 formulation (inertias augmented inside a tree pass per Newton iteration)
+#else
+    static constexpr bool kHM = true;
+#endif
     // Active rows sit in two LDS stacks in detection order (ascending dof / ascending capsule end):
     // limit rows (D, aref) and contact slots (point, D, aref_n, aref_t).  The solver passes walk the
     // constraints in DESCENDING order, so they pop the stacks top-down and always have the rows of the
@@ -328,6 +357,7 @@ struct Lean {
     uint32_t lim_on, lim_hi;             // bit j: limit row of dof j active / it is the upper limit
     uint32_t cand_on;                    // bit c: floor candidate (capsule end) c is in contact and owns a slot
     int nslot, nlimrow;                  // heights of the two stacks
+    bool was_constrained;                // the last dynamics evaluation had active rows (its qacc came from the solver)
     uint32_t pair_on;
     unsigned status;
     int newton_iters;
@@ -596,9 +626,21 @@ struct Lean {
             }
             // ---- capsule-end / floor contacts of this body's geoms ----
             if (M::HAS_FLOOR) {
+#ifndef MBRL_NO_FAST_FLOOR_TEST
+                // Broad phase, two fused multiply-adds per capsule end and ONE test per capsule: the height of the end's
+                // sphere centre above the floor against radius + margin.  A capsule whose ends are both clear (the usual
+                // case) costs nothing else; the exact distance -- MuJoCo's expression, with its own rounding -- decides
+                // inside.  The broad phase is widened by 1e-9 so that it can never reject what the exact test accepts.
+                const T zb = (Ob + pb[b]) - M::FLOOR_Z;
+#endif
                 MBRL_UNROLL
                 for (int g = 0; g < M::NGEOM; g++) {
                     if (M::g_body[g] != b || !M::c_on[g]) continue;
+#ifndef MBRL_NO_FAST_FLOOR_TEST
+                    const T h0 = t_fma(cc, T(M::g_ea[g][1]), t_fma(ss, T(M::g_ea[g][0]), zb));
+                    const T h1 = t_fma(cc, T(M::g_eb[g][1]), t_fma(ss, T(M::g_eb[g][0]), zb));
+                    if (!MBRL_RARE(t_val(t_min(h0, h1)) < M::g_rad[g] + M::c_margin[g] + 1e-9)) continue;
+#endif
                     MBRL_UNROLL
                     for (int e = 0; e < 2; e++) {
                         const double la = e ? M::g_eb[g][0] : M::g_ea[g][0], lb = e ? M::g_eb[g][1] : M::g_ea[g][1];
@@ -1078,6 +1120,195 @@ struct Lean {
         }
     }
 
+    // ------------------------------------------------------------------ explicit rows on the shared inertia HM
+    // Row of a point constraint at P (relative to O) on body b: along the floor normal  Jn[j] = w_n . S_j  with
+    // w_n = (Pa, 0, 1), along the tangent  Jt[j] = w_t . S_j  with w_t = (-Pb, 1, 0).  For a planar tree these are just
+    // lever arms: a hinge j gives  sgn_j (Pa + ra_j)  and  -sgn_j (Pb + rb_j),  a slide along a gives (0, 1), along b (1, 0).
+    // Only the dofs that move b are filled in; the slides' constants are folded where they are used.
+    MBRL_HD void point_rows(int b, T Pa, T Pb, T *Jn, T *Jt) const {
+        MBRL_UNROLL
+        for (int j = 0; j < NV; j++) {
+            if (!TP::T.moves[j][b] || M::dof_type[j] != 2) continue;
+            Jn[j] = M::dof_sgn[j] * (Pa + ra[j]);
+            Jt[j] = -M::dof_sgn[j] * (Pb + rb[j]);
+        }
+    }
+    // (Jn . x, Jt . x) over the dofs that move b
+    MBRL_HD void point_vel(int b, const T *Jn, const T *Jt, const T *x, T &vn, T &vt) const {
+        vn = T(0.0); vt = T(0.0);
+        bool fn = true, ft = true;          // first term: assign instead of adding to zero
+        MBRL_UNROLL
+        for (int j = 0; j < NV; j++) {
+            if (!TP::T.moves[j][b]) continue;
+            if (M::dof_type[j] == 0) { vt = ft ? x[j] : vt + x[j]; ft = false; }
+            else if (M::dof_type[j] == 1) { vn = fn ? x[j] : vn + x[j]; fn = false; }
+            else {
+                vn = fn ? Jn[j] * x[j] : vn + Jn[j] * x[j]; fn = false;
+                vt = ft ? Jt[j] * x[j] : vt + Jt[j] * x[j]; ft = false;
+            }
+        }
+    }
+
+    // One Newton iteration's constraint pass on the shared inertia: residuals at x, the active-row masks, jtf = J^T f and
+    // H = HM + J^T D J (lower triangle).  No tree walk: every active row adds its force and its rank-one (contacts: rank-
+    // two) block explicitly, on the dofs that move its body.  Stacks are popped top-down: contacts in descending candidate
+    // order, then limits in descending dof order.
+    MBRL_HD void newton_rows(const T *x, T (*H)[NV], T *jtf, uint32_t &lm, CM &cm) const {
+        lm = 0; cm = 0;
+        MBRL_UNROLL
+        for (int i = 0; i < NV; i++) {
+            jtf[i] = T(0.0);
+            MBRL_UNROLL
+            for (int j = 0; j <= i; j++)
+                if (TP::T.dof_anc[j][i]) H[i][j] = HM[i][j];
+        }
+        // ---- capsule/capsule pairs (b1 is an ancestor of b2: the row acts on the dofs between them) ----
+        MBRL_UNROLL
+        for (int k = 0; k < M::NPAIR; k++) {
+            if (pair_on & (1u << k)) {
+                const int o = LY::OP + 5 * k;
+                const T w0 = mem.ld(o), w1 = mem.ld(o + 1), w2 = mem.ld(o + 2), D = mem.ld(o + 3), aref = mem.ld(o + 4);
+                T rr[NV];
+                T jar = -aref;
+                MBRL_UNROLL
+                for (int j = 0; j < NV; j++) {
+                    if (!TP::T.between[k][j]) continue;
+                    const Sp<T> Sj = Scol(j);
+                    rr[j] = w0 * Sj.w + w1 * Sj.a + w2 * Sj.b;
+                    jar = jar + rr[j] * x[j];
+                }
+                if (t_val(jar) < 0.0) {
+                    lm |= 1u << (NV + k);
+                    const T f = -D * jar;
+                    MBRL_UNROLL
+                    for (int i = 0; i < NV; i++) {
+                        if (!TP::T.between[k][i]) continue;
+                        jtf[i] = jtf[i] + f * rr[i];
+                        const T di = D * rr[i];
+                        MBRL_UNROLL
+                        for (int j = 0; j <= i; j++) {
+                            if (!TP::T.between[k][j]) continue;
+                            H[i][j] = H[i][j] + di * rr[j];
+                        }
+                    }
+                }
+            }
+        }
+        // ---- floor contacts ----
+        if (M::HAS_FLOOR) {
+            if (MBRL_RARE(cand_on != 0)) {
+                Pop<LY::OS, 5> cs;
+                cs.start(mem, nslot);
+                int csh = 3 * (nslot - 1);          // bit position of the top slot's rows in `cm`
+                MBRL_UNROLL
+                for (int g = M::NGEOM - 1; g >= 0; g--) {
+                    if (!M::c_on[g]) continue;
+                    if (!MBRL_RARE(cand_on & (3u << TP::T.cand_rank[g][0]))) continue;   // neither end of this capsule
+                    const int b = M::g_body[g];
+                    MBRL_UNROLL
+                    for (int e = 1; e >= 0; e--) {
+                        if (cand_on & (1u << TP::T.cand_rank[g][e])) {
+                            T Pa = cs.cur[0], Pb = cs.cur[1];
+                            const T D = cs.cur[2], arn = cs.cur[3], art = cs.cur[4];
+                            const int sh = csh;
+                            csh -= 3;
+                            cs.next(mem);
+                            MBRL_ANCHOR(Pa); MBRL_ANCHOR(Pb);
+                            T Jn[NV], Jt[NV], vn, vt;
+                            point_rows(b, Pa, Pb, Jn, Jt);
+                            point_vel(b, Jn, Jt, x, vn, vt);
+                            const T rn = vn - arn, rt = vt - art;
+                            // Pyramid rows n + mu t, n - mu t, n (weight 2) in the (n, t) basis.  Branch-free: an inactive
+                            // row (residual >= 0) contributes min(r, 0) = 0 and D_row = 0.
+                            T fn, ft, dnn, dnt, dtt;
+                            uint32_t rows;
+                            if (M::c_dim[g] == 1) {
+                                const bool on = t_val(rn) < 0.0;
+                                rows = on ? 4u : 0u;
+                                dnn = on ? D : T(0.0);
+                                fn = -D * t_min(rn, T(0.0)); ft = T(0.0); dnt = T(0.0); dtt = T(0.0);
+                            } else {
+                                const double mu = M::c_mu[g];
+                                const T r0 = rn + mu * rt, r1 = rn - mu * rt;
+                                const bool on0 = t_val(r0) < 0.0, on1 = t_val(r1) < 0.0, on2 = t_val(rn) < 0.0;
+                                rows = (on0 ? 1u : 0u) | (on1 ? 2u : 0u) | (on2 ? 4u : 0u);
+                                const T d0 = on0 ? D : T(0.0), d1 = on1 ? D : T(0.0), d2 = on2 ? T(2.0) * D : T(0.0);
+                                const T m0 = t_min(r0, T(0.0)), m1 = t_min(r1, T(0.0)), m2 = t_min(rn, T(0.0));
+                                fn = -D * ((m0 + m1) + T(2.0) * m2);
+                                ft = (-mu * D) * (m0 - m1);
+                                dnn = (d0 + d1) + d2;
+                                dnt = mu * (d0 - d1);
+                                dtt = (mu * mu) * (d0 + d1);
+                            }
+                            cm |= CM(rows) << sh;
+                            const bool tang = M::c_dim[g] != 1;
+                            // force and Hessian block on the dofs that move b:  An = dnn Jn + dnt Jt,  At = dnt Jn + dtt Jt,
+                            // H[i][j] += An_i Jn_j + At_i Jt_j  (slides: Jn, Jt are 0 / 1)
+                            MBRL_UNROLL
+                            for (int i = 0; i < NV; i++) {
+                                if (!TP::T.moves[i][b]) continue;
+                                T An, At;
+                                if (M::dof_type[i] == 0) { An = dnt; At = dtt; if (tang) jtf[i] = jtf[i] + ft; }
+                                else if (M::dof_type[i] == 1) { An = dnn; At = dnt; jtf[i] = jtf[i] + fn; }
+                                else {
+                                    if (tang) { An = dnn * Jn[i] + dnt * Jt[i]; At = dnt * Jn[i] + dtt * Jt[i]; jtf[i] = (jtf[i] + fn * Jn[i]) + ft * Jt[i]; }
+                                    else { An = dnn * Jn[i]; At = T(0.0); jtf[i] = jtf[i] + fn * Jn[i]; }
+                                }
+                                MBRL_UNROLL
+                                for (int j = 0; j <= i; j++) {
+                                    if (!TP::T.moves[j][b]) continue;
+                                    if (M::dof_type[j] == 0) { if (tang) H[i][j] = H[i][j] + At; }
+                                    else if (M::dof_type[j] == 1) H[i][j] = H[i][j] + An;
+                                    else if (tang) H[i][j] = (H[i][j] + An * Jn[j]) + At * Jt[j];
+                                    else H[i][j] = H[i][j] + An * Jn[j];
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // ---- joint limits ----
+        if (LY::NLIM > 0) {
+            if (MBRL_RARE(lim_on != 0)) {
+                Pop<LY::OL, 2> ls;
+                ls.start(mem, nlimrow);
+                MBRL_UNROLL
+                for (int i = NV - 1; i >= 0; i--) {
+                    if (!M::limited[i]) continue;
+                    if (lim_on & (1u << i)) {
+                        T D = ls.cur[0], aref = ls.cur[1];
+                        ls.next(mem);
+                        MBRL_ANCHOR(aref);
+                        const bool up = (lim_hi >> i) & 1u;
+                        const T jar = (up ? -x[i] : x[i]) - aref;
+                        if (t_val(jar) < 0.0) {
+                            lm |= 1u << i;
+                            const T f = -D * jar;
+                            jtf[i] = jtf[i] + (up ? -f : f);
+                            H[i][i] = H[i][i] + D;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // y = HM x = (M + arm) x  from the stored lower triangle (tree-sparse, symmetric)
+    MBRL_HD void mass_mul_hm(const T *x, T *y) const {
+        MBRL_UNROLL
+        for (int i = 0; i < NV; i++) y[i] = HM[i][i] * x[i];
+        MBRL_UNROLL
+        for (int i = 0; i < NV; i++) {
+            MBRL_UNROLL
+            for (int j = 0; j < i; j++) {
+                if (!TP::T.dof_anc[j][i]) continue;
+                y[i] = y[i] + HM[i][j] * x[j];
+                y[j] = y[j] + HM[i][j] * x[i];
+            }
+        }
+    }
+
     // y = (M + arm) x
     MBRL_HD void mass_mul(const T *x, T *y) const {
         Sp<T> Vs[NB], Fm[NB];
@@ -1104,12 +1335,18 @@ struct Lean {
         auto body = [&](const int it) -> bool {       // one Newton iteration; true: leave the loop
             MBRL_LOOP_FENCE;
             MBRL_OPAQUE(cand_on); MBRL_OPAQUE(lim_on);   // keep the per-row bit tests inside the loop
+#ifdef MBRL_OPAQUE_MORE
+            MBRL_OPAQUE(lim_hi); MBRL_OPAQUE(nslot); MBRL_OPAQUE(nlimrow);   // ... and the stack offsets / limit sides
+#endif
             T H[NV][NV], jtf[NV], sx[NV];
             uint32_t lm;
             CM cm;
             MBRL_PHASE(8);
             newton_iters = it + 1;
-            newton_pass<true>(qacc, H, jtf, lm, cm);
+            MBRL_MARK("pass_begin");
+            if constexpr (kHM) newton_rows(qacc, H, jtf, lm, cm);
+            else newton_pass<true>(qacc, H, jtf, lm, cm);
+            MBRL_MARK("pass_end");
             MBRL_PIN(jtf, NV);
             MBRL_UNROLL
             for (int i = 0; i < NV; i++) {
@@ -1125,6 +1362,7 @@ struct Lean {
                 return true;
             }
             plm = lm; pcm = cm;
+            MBRL_MARK("factor_begin");
             const bool ok = factor(H);
             if (!ok) { status |= ST_NONFINITE; return true; }
             MBRL_UNROLL
@@ -1134,6 +1372,7 @@ struct Lean {
             MBRL_UNROLL
             for (int j = 0; j < NV; j++) { snorm = snorm + sx[j] * sx[j]; qnorm = qnorm + qacc[j] * qacc[j]; a1 = a1 + sx[j] * gs[j]; }
             MBRL_PIN(sx, NV);
+            MBRL_MARK("solve_end");
             MBRL_PHASE(3);
             if (!t_finite(snorm)) { status |= ST_NONFINITE; return true; }
             if (t_val(t_sqrt(snorm)) <= 1e-15 * (1.0 + t_val(t_sqrt(qnorm)))) {
@@ -1144,11 +1383,13 @@ struct Lean {
             }
             // exact line search: root of the piecewise-linear derivative (safeguarded Newton)
             T Ms[NV];
-            mass_mul(sx, Ms);
+            if constexpr (kHM) mass_mul_hm(sx, Ms);
+            else mass_mul(sx, Ms);
             T a2 = T(0.0);
             MBRL_UNROLL
             for (int j = 0; j < NV; j++) a2 = a2 + sx[j] * Ms[j];
             MBRL_PIN(Ms, NV);
+            MBRL_MARK("ms_end");
             MBRL_PHASE(4);
             if (it < kUnitIters<M>) {
                 MBRL_UNROLL
@@ -1215,18 +1456,38 @@ struct Lean {
     // ------------------------------------------------------------------ mj_forward
     MBRL_HD void forward() {
         MBRL_PHASE(8);
+        MBRL_MARK("sweep_begin");
         {
             Sp<T> F[NB];
             sweep(F);
             smooth_forces(F);
         }
         MBRL_PIN(fsm, NV); MBRL_PIN(ra, NV); MBRL_PIN(rb, NV); MBRL_PIN(ha, NB); MBRL_PIN(hb, NB); MBRL_PIN(IO, NB);
+        MBRL_MARK("sweep_end");
         MBRL_PHASE(0);
         const bool constrained = (lim_on | cand_on | pair_on) != 0;
+        was_constrained = constrained;
         // Start of the solver: the unconstrained acceleration.  (Starting from the previous mj_step's solution was
         // measured: it does not lower the number of Newton passes on on-trajectory HalfCheetah states, 2.67 vs 2.57
         // per constrained step.)
-        if (M::RK4 || !M::ANY_DAMPING || constrained) {   // Euler with implicit damping needs qacc only for the solver
+        if constexpr (kHM) {
+            T arm[NV];
+            MBRL_UNROLL
+            for (int j = 0; j < NV; j++) arm[j] = T(M::arma[j]);
+            crba(HM, arm);                                 // once per dynamics evaluation; see the member's comment
+            if (M::RK4 || !M::ANY_DAMPING || constrained) {   // Euler with implicit damping needs qacc only for the solver
+                T H[NV][NV];
+                MBRL_UNROLL
+                for (int i = 0; i < NV; i++) {
+                    qacc[i] = fsm[i];
+                    MBRL_UNROLL
+                    for (int j = 0; j <= i; j++)
+                        if (TP::T.dof_anc[j][i]) H[i][j] = HM[i][j];
+                }
+                if (!factor(H)) status |= ST_NONFINITE;
+                solve(H, qacc);
+            }
+        } else if (M::RK4 || !M::ANY_DAMPING || constrained) {   // Euler with implicit damping needs qacc only for the solver
             T H[NV][NV], arm[NV];
             MBRL_UNROLL
             for (int j = 0; j < NV; j++) { arm[j] = T(M::arma[j]); qacc[j] = fsm[j]; }
@@ -1235,6 +1496,7 @@ struct Lean {
             solve(H, qacc);
         }
         MBRL_PIN(qacc, NV);
+        MBRL_MARK("unconstrained_end");
         MBRL_PHASE(1);
         MBRL_UNROLL
         for (int j = 0; j < NV; j++) fcon[j] = T(0.0);
@@ -1242,17 +1504,35 @@ struct Lean {
         ls_iters = 0;
         if (constrained) solve_constraints();
         MBRL_PIN(qacc, NV); MBRL_PIN(fcon, NV);
+        MBRL_MARK("solver_end");
         MBRL_PHASE(6);
     }
 
     // ------------------------------------------------------------------ integrators
     MBRL_HD void euler() {
+        MBRL_MARK("euler_begin");
         T x[NV];
         if (M::ANY_DAMPING) {
             T H[NV][NV], dg[NV];
             MBRL_UNROLL
             for (int j = 0; j < NV; j++) { dg[j] = T(M::arma[j]) + T(M::DT) * M::damp[j]; x[j] = fsm[j] + fcon[j]; }
-            crba(H, dg);
+            if constexpr (kHM) {        // M + arm is at hand: add h D on the diagonal
+#ifndef MBRL_NO_STATIONARY_FORCE
+                // Total force of a constrained evaluation: at the solver's fixed point  (M + arm) qacc = qfrc_smooth + J^T f,
+                // so it is HM qacc -- neither qfrc_smooth nor the constraint force has to outlive the solver.
+                if (was_constrained) mass_mul_hm(qacc, x);
+                else {
+                    MBRL_UNROLL
+                    for (int j = 0; j < NV; j++) x[j] = fsm[j];
+                }
+#endif
+                MBRL_UNROLL
+                for (int i = 0; i < NV; i++) {
+                    MBRL_UNROLL
+                    for (int j = 0; j <= i; j++)
+                        if (TP::T.dof_anc[j][i]) H[i][j] = (j == i && M::damp[i] != 0.0) ? HM[i][i] + T(M::DT * M::damp[i]) : HM[i][j];
+                }
+            } else crba(H, dg);
             if (!factor(H)) status |= ST_NONFINITE;
             solve(H, x);
         } else {
@@ -1265,6 +1545,7 @@ struct Lean {
             mem.st(LY::OV + j, vn);
             mem.st(LY::OQ + j, mem.ld(LY::OQ + j) + M::DT * vn);
         }
+        MBRL_MARK("euler_end");
     }
 
     static constexpr int key_first_lim() { int f = 0; while (f < NV - 1 && !M::limited[f]) f++; return f; }

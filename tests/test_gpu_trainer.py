@@ -294,11 +294,18 @@ def test_two_ranks_on_the_gpu_train_like_one(weights, tmp_path):
                               env=dict(env, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
                                        MASTER_PORT=str(port), MBRL_DIST_BACKEND="gloo")) for r in range(2)]
     assert [p.wait(timeout=240) for p in procs] == [0, 0]
-    one = torch.load(tmp_path / "HalfCheetahEnv" / "one" / "weights" / "iter_2.pth", weights_only=True)
-    two = torch.load(tmp_path / "HalfCheetahEnv" / "two" / "weights" / "iter_2.pth", weights_only=True)
     assert sorted(os.listdir(tmp_path / "HalfCheetahEnv" / "two" / "results")) == ["output_0"]
-    for k in one:
-        assert torch.allclose(one[k].cpu(), two[k].cpu(), rtol=1e-9, atol=1e-12), k
+    # Same draws and the same arithmetic per episode; only the gradient sum runs in another order.  After the first update
+    # the parameters therefore agree to rounding.  From there a contact model amplifies that rounding through the 1/eps of
+    # its finite differences (a perturbed rollout that grazes a contact) and through Adam's normalisation:
+    # the third update is compared at the level that amplification reaches, not at rounding.
+    for it, rtol, atol in ((0, 1e-9, 1e-12), (2, 1e-7, 1e-9)):      # measured: 0 and 1e-10
+        one = torch.load(tmp_path / "HalfCheetahEnv" / "one" / "weights" / ("iter_%d.pth" % it), weights_only=True)
+        two = torch.load(tmp_path / "HalfCheetahEnv" / "two" / "weights" / ("iter_%d.pth" % it), weights_only=True)
+        for k in one:
+            d = float((one[k].cpu() - two[k].cpu()).abs().max())
+            print("two ranks vs one, %s, update %d, %s: max |diff| %.3e" % (weights, it, k, d))
+            assert torch.allclose(one[k].cpu(), two[k].cpu(), rtol=rtol, atol=atol), (it, k, d)
 
 
 @pytest.mark.timeout(300)

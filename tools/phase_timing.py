@@ -18,7 +18,7 @@ def build():
     import mbrl_amd
     from mbrl_amd import build as b
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    b.compile_lib(OUT, ["-DMBRL_PHASE_TIMING"])
+    b.compile_lib(OUT, ["-DMBRL_PHASE_TIMING", "-DMBRL_ONLY_ENV=%d" % int(os.environ.get("ONLY_ENV", "5"))] + sys.argv[2:])
 
 
 def main():
@@ -32,15 +32,18 @@ def main():
     q, v, c = workloads.s2(eng, N, seed=0)
     out = eng.fd_jacobians(q, v, c)
     torch.cuda.synchronize()
-    buf = (C.c_ulonglong * 16)()
+    buf = (C.c_ulonglong * 32)()
     assert eng.L.mbrl_debug_phase_read(buf, 1) == 0
     eng.fd_jacobians(q, v, c, out=out)
     torch.cuda.synchronize()
     assert eng.L.mbrl_debug_phase_read(buf, 0) == 0
-    tot = float(sum(buf))
+    tot = float(sum(buf[:16]))
+    mark = buf[10] / max(buf[26], 1)          # cost of one mark (phase 10 = two marks back to back)
     for k in range(16):
         if buf[k]:
-            print("%-48s %6.2f %%" % (NAMES.get(k, "phase %d" % k), 100.0 * buf[k] / tot))
+            n = buf[16 + k]
+            print("%-48s %6.2f %%   %9d times   %8.1f clocks each (mark cost %.0f not subtracted)" %
+                  (NAMES.get(k, "phase %d" % k), 100.0 * buf[k] / tot, n, buf[k] / max(n, 1), mark))
 
 
 if __name__ == "__main__":
