@@ -155,9 +155,23 @@ class Linearisation:
             pass
 
     def wait(self):
-        """Make the current stream wait for everything submitted."""
+        """Make the current stream wait for everything submitted.  MBRL_FD_WATCHDOG_S=<seconds> (off by default: it
+        blocks the host) turns a side stream that stops making progress into an error that names what was outstanding,
+        instead of a run that sits in its next host synchronisation for ever ("the stalled run")."""
         done = torch.cuda.Event()
         done.record(self.stream)
+        limit = float(os.environ.get("MBRL_FD_WATCHDOG_S", "0") or 0)
+        if limit > 0:
+            import time
+            t0 = time.monotonic()
+            while not done.query():
+                if time.monotonic() - t0 > limit:
+                    raise lib.MbrlError(
+                        "linearisation side stream made no progress for %.0f s: %d of %d time steps submitted in chunks of "
+                        "%d, main stream %#x, side stream %#x (rejected candidates: %s)" %
+                        (limit, self.next_t, self.H, self.chunk, torch.cuda.current_stream(self.eng.device).cuda_stream,
+                         self.stream.cuda_stream, getattr(self.eng, "side_stream_rejected", None)))
+                time.sleep(0.001)
         torch.cuda.current_stream(self.eng.device).wait_event(done)
 
 
