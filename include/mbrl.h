@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MBRL_ABI_VERSION 8
+#define MBRL_ABI_VERSION 9
 
 /* per-unit status bits (replace mujoco-py's MujocoException / the reference's asserts,
  * backward.py:371,374) */
@@ -128,6 +128,19 @@ int mbrl_step_record(const mbrl_model *m, int64_t N, const double *qpos, const d
                      double *qpos_next, double *qvel_next, double *reward, uint32_t *status, void *plan, int64_t plan_bytes,
                      int64_t plan_units, int64_t unit_offset, void *hip_stream);
 int mbrl_fd_plan_finish(const mbrl_model *m, int64_t plan_units, const double *reward, void *plan, int64_t plan_bytes,
+                        void *hip_stream);
+
+/* T consecutive mbrl_step_record calls in ONE launch, for rollouts whose actions are known ahead -- the reference's
+ * default policy is an open-loop action sequence (cfg.MODEL.POLICY.NETWORK = False, model/blocks/policy/strategies.py:
+ * 402-408), so the loop `for t: state, reward = model(state)` of model/engine/trainer.py:63-65 needs no state feedback.
+ * Time-major buffers: qpos [T+1, B, nq] and qvel [T+1, B, nv] (slice 0 = the start states, step k reads slice k and
+ * writes slice k + 1), ctrl [T, B, nu], reward [T, B], status [T, B] (may be NULL).  With plan != NULL step k records
+ * its B units as units [unit_offset + k B, unit_offset + (k + 1) B) of a plan for plan_units units, exactly as
+ * mbrl_step_record does (plan == NULL: mbrl_step).  A wave keeps its 64 episodes for all T steps, so the launch lasts
+ * as long as the slowest wave's SUM over the steps rather than the sum of every step's slowest wave.  Results are those
+ * of the T single-step launches bit for bit. */
+int mbrl_rollout_record(const mbrl_model *m, int64_t B, int T, double *qpos, double *qvel, const double *ctrl, double *reward,
+                        uint32_t *status, void *plan, int64_t plan_bytes, int64_t plan_units, int64_t unit_offset,
                         void *hip_stream);
 
 /* NO COUNTERPART IN THE REFERENCE.  For callers that cannot allocate device memory (code under HIP graph capture, tight

@@ -484,6 +484,65 @@ __global__ __launch_bounds__(64) void spin_kernel(unsigned long long ticks) {
     if (ticks == ~0ull) spin_pad[threadIdx.x] = 0;     // (keeps the allocation; never true for a real probe)
 }
 
+// mbrl_rollout_record: T consecutive env steps of B episodes in ONE launch, time-major buffers
+//   Q [T+1, B, nq], V [T+1, B, nv]: step k reads slice k and writes slice k + 1;  C [T, B, nu];  R, status [T, B].
+// Lane = episode, as in a step launch; a wave keeps its 64 episodes for all T steps, so the launch lasts as long as the
+// slowest wave's SUM over the steps instead of the sum of every step's slowest wave (and T - 1 launch gaps go away).
+// Every step is the very lane_rollout call a step launch makes, inputs read back from the slices this lane wrote one
+// step earlier, so the states, rewards, status words and recorded plan entries are those of T mbrl_step_record
+// launches bit for bit.  Units with more than eight floor contacts are re-run in the wave, as in a step launch.
+template <class M>
+__global__ __launch_bounds__(kBlock) void steps_kernel(int64_t B, int T, int frame_skip, int mode_flags, double *Q, double *V,
+                                                        const double *__restrict__ C, double *__restrict__ R,
+                                                        uint32_t *__restrict__ status, char *__restrict__ plan,
+                                                        int64_t plan_units, int64_t unit_offset) {
+    using LY = Layout<M>;
+    constexpr int NV = M::NV, NU = M::NU, NS = 2 * NV, ROW = NS + 1;
+    __shared__ double lds[LY::NMEM * kBlock];
+    const int t = threadIdx.x;
+    const int64_t b = int64_t(blockIdx.x) * kBlock + t;
+    const bool live = b < B;
+    const int64_t ep = live ? b : 0;
+    for (int k = 0; k < T; k++) {
+        const double *qk = Q + int64_t(k) * B * NV, *vk = V + int64_t(k) * B * NV, *ck = C + int64_t(k) * B * NU;
+        double o[ROW];
+        unsigned st = 0;
+        uint64_t key = 0;
+        if (live) lane_rollout<M, 8, kBlock>(lds + t, ep, -1, 0.0, false, false, frame_skip, 1, qk, vk, ck, nullptr, o, st, key);
+        if constexpr (kNeedsRedo<M>) {
+            unsigned long long need = __builtin_amdgcn_ballot_w64(live && ((st & ST_OVERFLOW) || (mode_flags & MODE_FORCE_WIDE)));
+            if (MBRL_RARE(need != 0 && !(mode_flags & MODE_NO_REDO))) {
+                constexpr int KALL = 32, LANES = 32;
+                static_assert(Layout<M, KALL>::NMEM * LANES <= LY::NMEM * kBlock, "the wide columns must fit this workgroup's LDS");
+                const bool redo = live && ((need >> t) & 1ull);
+                for (int c = 0; c < 2; c++) {
+                    const bool mine = redo && (t >> 5) == c;
+                    if (__builtin_amdgcn_ballot_w64(mine) == 0) continue;
+                    if (mine) lane_rollout<M, KALL, LANES>(lds + (t & 31), ep, -1, 0.0, false, false, frame_skip, 1, qk, vk, ck, nullptr, o, st, key);
+                }
+            }
+        }
+        if (live) {
+            double *qn = Q + int64_t(k + 1) * B * NV + ep * NV, *vn = V + int64_t(k + 1) * B * NV + ep * NV;
+#pragma unroll
+            for (int j = 0; j < NV; j++) { qn[j] = o[j]; vn[j] = o[NV + j]; }
+            R[int64_t(k) * B + ep] = o[NS];
+            if (status) status[int64_t(k) * B + ep] = st;
+            if (plan) {
+                const int64_t u = unit_offset + int64_t(k) * B + ep;
+                const PlanOffsets po(plan_units, NS);
+                reinterpret_cast<uint64_t *>(plan + po.key_in)[u] = key;
+                double *ns = reinterpret_cast<double *>(plan + po.nom_s) + u * NS;
+#pragma unroll
+                for (int j = 0; j < NS; j++) ns[j] = o[j];
+            }
+        }
+        // the next step reads what this one stored (same lane, same addresses): keep the order explicit
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // status words start from zero (the rollout waves OR into them)
 __global__ __launch_bounds__(256) void zero_words_kernel(uint32_t *__restrict__ w, int64_t n) {
     const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
@@ -716,6 +775,13 @@ static bool sort_scratch_bytes(int64_t n, size_t &bytes) {
     return true;
 }
 
+template <class M>
+static void launch_steps(const mbrl_model *m, int64_t blocks, hipStream_t st, int64_t B, int T, int flags, double *qpos, double *qvel,
+                         const double *ctrl, double *reward, uint32_t *status, char *plan, int64_t plan_units, int64_t unit_offset) {
+    hipLaunchKernelGGL((steps_kernel<M>), dim3((unsigned)blocks), dim3(kBlock), 0, st, B, T, m->frame_skip, flags, qpos, qvel, ctrl,
+                       reward, status, plan, plan_units, unit_offset);
+}
+
 static bool plan_layout(int64_t N, int ns, hipStream_t, PlanLayout &L) {
     L.sort_tmp = PlanOffsets(N, ns).end;
     if (!sort_scratch_bytes(N, L.sort_bytes)) return false;
@@ -934,6 +1000,33 @@ int mbrl_step_record(const mbrl_model *m, int64_t N, const double *qpos, const d
                                                       w + sizeof(uint64_t) * size_t(unit_offset), PLAN_RECORD)));
     if (rc) return fail(-10, "mbrl_step_record: clearing the status words failed");
     return check_launch(m, "mbrl_step_record");
+}
+
+int mbrl_rollout_record(const mbrl_model *m, int64_t B, int T, double *qpos, double *qvel, const double *ctrl, double *reward,
+                        uint32_t *status, void *plan, int64_t plan_bytes, int64_t plan_units, int64_t unit_offset,
+                        void *hip_stream) {
+    if (!m) return fail(-1, "mbrl_rollout_record: null model");
+    if (B < 0 || T < 0 || plan_units < 0 || unit_offset < 0) return fail(-6, "mbrl_rollout_record: negative size");
+    if (B == 0 || T == 0) return 0;
+    if (!qpos || !qvel || !ctrl || !reward) return fail(-1, "mbrl_rollout_record: null buffer");
+    if (B > (int64_t(1) << 31) || int64_t(T) * B > (int64_t(1) << 40)) return fail(-6, "mbrl_rollout_record: batch too large");
+    if (hipSetDevice(m->device) != hipSuccess) return fail(-4, "mbrl_rollout_record: hipSetDevice failed");
+    hipStream_t st = (hipStream_t)hip_stream;
+    char *w = static_cast<char *>(plan);
+    if (plan) {
+        if (unit_offset + int64_t(T) * B > plan_units)
+            return fail(-6, "mbrl_rollout_record: units [offset, offset + T * B) must lie inside the plan");
+        if (plan_units > (int64_t(1) << 31)) return fail(-6, "mbrl_rollout_record: plan too large");
+        if (reinterpret_cast<uintptr_t>(plan) & 255) return fail(-7, "mbrl_rollout_record: the plan buffer must be 256-byte aligned");
+        PlanLayout L;
+        if (!plan_layout(plan_units, m->nq + m->nv, st, L)) return fail(-10, "mbrl_rollout_record: sort size query failed");
+        if (plan_bytes < int64_t(L.total))
+            return fail(-8, "mbrl_rollout_record: plan buffer too small%s (need %lld bytes, see mbrl_fd_plan_bytes)", "", (long long)L.total);
+    }
+    const int64_t blocks = (B + kBlock - 1) / kBlock;
+    const int flags = g_debug_flags.load(std::memory_order_relaxed);
+    MBRL_DISPATCH(m->env_id, (launch_steps<M>(m, blocks, st, B, T, flags, qpos, qvel, ctrl, reward, status, w, plan_units, unit_offset)));
+    return check_launch(m, "mbrl_rollout_record");
 }
 
 int mbrl_fd_plan_finish(const mbrl_model *m, int64_t plan_units, const double *reward, void *plan, int64_t plan_bytes,

@@ -168,6 +168,26 @@ class FdEngine:
                                               _ptr(reward), _ptr(status), _ptr(buf), buf.numel(), int(plan_units),
                                               int(unit_offset), self._stream()))
 
+    def rollout_record(self, Q, V, A, R, S, t0, t1, plan=None, plan_units=0, unit_offset=0):
+        """Env steps t0 .. t1-1 of a time-major rollout in ONE launch (mbrl_rollout_record): Q [H+1, B, nq], V [H+1, B, nv],
+        A [H, B, nu], R [H, B], S [H, B] are the rollout's own contiguous buffers; step t reads slice t and writes slice
+        t + 1.  With `plan` the steps record their units [unit_offset + (t - t0) B, ...) into it like step_record."""
+        B, T = Q.shape[1], int(t1 - t0)
+        for t, w in ((Q, self.nq), (V, self.nv), (A, self.nu)):
+            if t.dim() != 3 or t.shape[1] != B or t.shape[2] != w or not t.is_contiguous() or t.dtype != torch.float64:
+                raise ValueError("rollout_record: expected contiguous float64 [*, %d, %d] buffers" % (B, w))
+        if not (0 <= t0 < t1 <= A.shape[0] and Q.shape[0] > t1 and V.shape[0] > t1 and R.shape[0] >= t1 and S.shape[0] >= t1):
+            raise ValueError("rollout_record: steps [%d, %d) outside the buffers" % (t0, t1))
+        if not (R.is_contiguous() and S.is_contiguous() and R.shape[1] == B and S.shape[1] == B):
+            raise ValueError("rollout_record: reward / status must be contiguous [H, B]")
+        buf = plan.buf if plan is not None else None
+        if plan is not None and (buf is None or plan.capacity < plan_units):
+            raise lib.MbrlError("rollout_record: reserve the plan for %d units first" % plan_units)
+        with torch.cuda.device(self.device):
+            lib.check(self.L.mbrl_rollout_record(self.h, B, T, _ptr(Q[t0]), _ptr(V[t0]), _ptr(A[t0]), _ptr(R[t0]), _ptr(S[t0]),
+                                                 _ptr(buf), buf.numel() if buf is not None else 0, int(plan_units),
+                                                 int(unit_offset), self._stream()))
+
     def plan_finish(self, plan, plan_units, reward):
         """Header + unit order of a plan recorded by step_record launches (mbrl_fd_plan_finish); `reward` [plan_units]
         is what those launches wrote.  fd_planned(..., plan=plan) runs on it."""

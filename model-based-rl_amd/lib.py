@@ -16,7 +16,7 @@ EPISODE_MAJOR, TIME_MAJOR = 0, 1
 
 SYMBOLS = ("mbrl_abi_version", "mbrl_model_create", "mbrl_model_destroy", "mbrl_model_dims", "mbrl_step",
            "mbrl_fd_jacobians", "mbrl_fd_jacobians_closed_loop", "mbrl_fd_plan_bytes", "mbrl_fd_plan",
-           "mbrl_fd_jacobians_planned", "mbrl_fd_jacobians_static", "mbrl_step_record", "mbrl_fd_plan_finish", "mbrl_vjp_scan", "mbrl_vjp_scan_layout", "mbrl_vjp_scan_sharded", "mbrl_lane_map", "mbrl_last_error")
+           "mbrl_fd_jacobians_planned", "mbrl_fd_jacobians_static", "mbrl_step_record", "mbrl_rollout_record", "mbrl_fd_plan_finish", "mbrl_vjp_scan", "mbrl_vjp_scan_layout", "mbrl_vjp_scan_sharded", "mbrl_lane_map", "mbrl_last_error")
 
 _lib = None
 vp = C.c_void_p
@@ -58,11 +58,12 @@ def load():
     L.mbrl_vjp_scan_sharded.argtypes = [vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64] + [vp] * 7 + [vp]
     L.mbrl_step_record.argtypes = [vp, C.c_int64] + [vp] * 7 + [vp, C.c_int64, C.c_int64, C.c_int64, vp]
     L.mbrl_fd_plan_finish.argtypes = [vp, C.c_int64, vp, vp, C.c_int64, vp]
+    L.mbrl_rollout_record.argtypes = [vp, C.c_int64, C.c_int] + [vp] * 5 + [vp, C.c_int64, C.c_int64, C.c_int64, vp]
     # test knobs outside include/mbrl.h (tests/test_gpu_overflow.py, tests/test_zz_no_alloc.py)
     L.mbrl_debug_set_flags.argtypes = [C.c_int]
     L.mbrl_debug_static_hold.argtypes = [vp, C.c_int, vp]
     L.mbrl_stream_probe_spin.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]     # engine.py: side-stream selection
-    if L.mbrl_abi_version() != 8:
+    if L.mbrl_abi_version() != 9:
         raise MbrlError("ABI version mismatch")
     _lib = L
     return L

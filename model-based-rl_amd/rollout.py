@@ -246,7 +246,25 @@ def rollout_with_policy(engine, agent, model_policy, s0, horizon, linearise=None
     if ahead is not None:
         A.copy_(ahead.detach())
     acts = []
-    for t in range(horizon):
+    # actions known ahead: the env steps of a whole chunk run in ONE launch (FdEngine.rollout_record).  Each wave keeps
+    # its episodes across the steps, so nothing waits for every step's slowest wave; same bits as step by step.
+    multi = ahead is not None and os.environ.get("MBRL_NO_MULTISTEP") is None and hasattr(engine, "rollout_record")
+    if multi:
+        span = lin.chunk if lin is not None else horizon
+        for t0 in range(0, horizon, span):
+            t1 = min(horizon, t0 + span)
+            rec = lin.recorder(t0) if lin is not None else None
+            if rec is not None:
+                engine.rollout_record(Q, V, A, R, S, t0, t1, plan=rec[0], plan_units=rec[1], unit_offset=rec[2])
+                for t in range(t0 + 1, t1):          # the chunk's plan is the same object for every step of it
+                    lin.recorder(t)
+            else:
+                engine.rollout_record(Q, V, A, R, S, t0, t1)
+            if lin is not None:
+                for buf in ((R, S) if t0 == 0 else ()):
+                    buf.record_stream(lin.stream)
+                lin.submit(Q, V, A, t1, R, S)
+    for t in (range(0) if multi else range(horizon)):
         agent.set_step_idx(t)
         if ahead is None:
             a = model_policy(torch.cat([Q[t], V[t]], dim=1).float()).double()

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert set(names) == set(lib.SYMBOLS)
     for n in names:
         assert getattr(L, n) is not None
-    assert L.mbrl_abi_version() == 8
+    assert L.mbrl_abi_version() == 9
 
 
 def test_error_paths_need_no_gpu():

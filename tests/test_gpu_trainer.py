@@ -365,3 +365,81 @@ def test_actions_ahead_of_the_rollout_train_bit_for_bit(tmp_path, monkeypatch):
         assert torch.equal(res[False][0][k], res[True][0][k]), k
     assert torch.equal(res[False][1], res[True][1]) and torch.equal(res[False][2], res[True][2])
     assert res[False][3] == res[True][3]
+
+
+@pytest.mark.parametrize("env", ["HalfCheetahEnv", "Walker2dEnv", "InvertedPendulumEnv"])
+def test_rollout_in_one_launch_is_the_step_launches_bit_for_bit(env):
+    """mbrl_rollout_record (T env steps of B episodes in one launch, time-major buffers) against T mbrl_step_record
+    launches: states, rewards, status words and the recorded plan entries (keys, nominal next states) are equal bit for
+    bit -- also for walkers lying flat, whose steps are re-run in the wave with full contact capacity -- and the plan
+    drives mbrl_fd_jacobians_planned to the Jacobians of the ordinary schedule."""
+    import torch
+    import mbrl_amd  # noqa: F401
+    from mbrl_amd import workloads
+    from mbrl_amd.engine import FdEngine
+    e = FdEngine(env)
+    B, T = 333, 5
+    q, v, _ = workloads.s2(e, B, seed=9, horizon=20)
+    if env == "Walker2dEnv":                       # a few flat-lying walkers among them (more than eight floor contacts)
+        from test_gpu_overflow import flat_states
+        fq, fv, _ = flat_states(env, 16, 2)
+        q[:16], v[:16] = torch.as_tensor(fq, device="cuda"), torch.as_tensor(fv, device="cuda")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    A = torch.clamp(0.5 * torch.randn((T, B, e.nu), generator=g, dtype=torch.float64), -1, 1).cuda()
+    z = lambda *s, dt=torch.float64: torch.zeros(s, dtype=dt, device="cuda")
+
+    def buffers():
+        Q, V = z(T + 1, B, e.nq), z(T + 1, B, e.nv)
+        Q[0], V[0] = q, v
+        return Q, V, z(T, B), z(T, B, dt=torch.int32), e.new_plan(T * B)
+
+    Q0, V0, R0, S0, p0 = buffers()
+    for t in range(T):
+        e.step_record(Q0[t], V0[t], A[t], Q0[t + 1], V0[t + 1], R0[t], S0[t], p0, T * B, t * B)
+    Q1, V1, R1, S1, p1 = buffers()
+    e.rollout_record(Q1, V1, A, R1, S1, 0, T, plan=p1, plan_units=T * B)
+    Q2, V2, R2, S2, _ = buffers()
+    e.rollout_record(Q2, V2, A, R2, S2, 0, 2)              # without a plan, in two pieces
+    e.rollout_record(Q2, V2, A, R2, S2, 2, T)
+    torch.cuda.synchronize()
+    for a, b, c in ((Q0, Q1, Q2), (V0, V1, V2), (R0, R1, R2), (S0, S1, S2)):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    assert int(S0.abs().sum()) == 0
+    outs = []
+    for plan, R in ((p0, R0), (p1, R1)):
+        e.plan_finish(plan, T * B, R.reshape(-1))
+        o = e.new_outputs(T * B)
+        o["status"].copy_(S0.reshape(-1))
+        e.fd_planned(Q0[:T].reshape(-1, e.nq), V0[:T].reshape(-1, e.nv), A.reshape(-1, e.nu), o, plan=plan)
+        outs.append(o)
+    ref = e.fd_jacobians(Q0[:T].reshape(-1, e.nq), V0[:T].reshape(-1, e.nv), A.reshape(-1, e.nu), planned=False)
+    torch.cuda.synchronize()
+    for k in ("dsds", "dsda", "drds", "drda", "status"):
+        assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(ref[k], outs[1][k]), k
+    from mbrl_amd import lib
+    with pytest.raises(lib.MbrlError):
+        e.rollout_record(Q1, V1, A, R1, S1, 0, T, plan=p1, plan_units=T * B, unit_offset=1)      # sticks out of the plan
+
+
+def test_multi_step_rollout_launches_train_bit_for_bit(tmp_path, monkeypatch):
+    """The trainer with an open-loop policy runs each chunk of env steps in one launch (rollout.rollout_with_policy ->
+    FdEngine.rollout_record); parameters, actions, log-probabilities and logged rows after three epochs are those of
+    the step-by-step launches."""
+    import torch
+    res = {}
+    for multi in (False, True):
+        if multi:
+            monkeypatch.delenv("MBRL_NO_MULTISTEP", raising=False)
+        else:
+            monkeypatch.setenv("MBRL_NO_MULTISTEP", "1")
+        for overlap in (0, 3):
+            agent, rows, d = _train(_cfg("HalfCheetahEnv", B=24, H=7, epochs=3, MODEL__FD_OVERLAP_STEPS=overlap), tmp_path,
+                                    "multi%d_%d" % (multi, overlap))
+            pol = agent.policy_net
+            res[multi, overlap] = ({k: v.cpu() for k, v in pol.state_dict().items()}, pol._clamped_action.cpu().clone(),
+                                   pol.log_prob.cpu().clone(), rows)
+    for overlap in (0, 3):
+        a, b = res[False, overlap], res[True, overlap]
+        for k in a[0]:
+            assert torch.equal(a[0][k], b[0][k]), (overlap, k)
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and a[3] == b[3]
