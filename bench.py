@@ -29,7 +29,8 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X spec: 256 CU x 4 SIMD x 16 fp64 FMA la
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 ENV = "HalfCheetahEnv"
 BATCH, HORIZON = 4096, 40
-FLOPS_PER_UNIT_RECORDED = 0.71e6  # fallback; re-counted live when the host twin is present
+FLOPS_PER_UNIT_RECORDED = 0.61e6  # fallback; re-counted live when the host twin is present
+FLOPS_PER_UNIT_ROUND2 = 0.71e6    # what round 2's formulation spent on the same Jacobians (profiles/r02_v15_bench.json)
 FLOP_SAMPLE_UNITS = 4096
 
 
@@ -312,6 +313,11 @@ def main():
         if "serial_plan" in extra:
             alone = extra["serial_plan"]["kernel_ms_alone"]
             extra["serial_plan"]["roofline_frac_alone"] = flops_used / (alone * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS
+            if a.fd_mode == 0 and not a.single_launch:
+                # the same launch priced with the flop count of round 2's formulation (the shared joint-space inertia of
+                # round 3 removed a fifth of the counted work together with the time): for comparison across rounds only
+                extra["serial_plan"]["roofline_frac_alone_at_round2_flop_count"] = \
+                    FLOPS_PER_UNIT_ROUND2 * (R - 1) / R * N / (alone * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS
         if extra:
             line["extra"] = extra
         if not a.no_cpu:

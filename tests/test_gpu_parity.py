@@ -5,7 +5,17 @@ largest entry (one-sided differences with eps = 1e-6 amplify the ~1e-15..1e-13 s
 between two different arithmetic formulations -- 3-D oracle with exact line search vs planar kernel with its
 own solver schedule -- by 1/eps; units whose active constraint set flips inside a perturbation are compared
 column-wise with the same bound since both sides see the same flip).  Measured margins (tests/parity_margins.py):
-worst Jacobian entry 1.5e-7 (HalfCheetah dsda), 1e-8 or better elsewhere; s' 1.5e-13 or better."""
+worst Jacobian entry 1.5e-7 (HalfCheetah dsda), 1e-8 or better elsewhere; s' 1.5e-13 or better.
+
+These tests SAMPLE the distribution (300-512 units per env).  Its tail is bounded by tests/test_gpu_parity_full.py on
+full-size batches (163 840 units) with the two-tier tolerance that north_star's "looser where contact is active" means
+here: >= 99.9 % of the units <= 5e-7 AND every unit <= 1e-5 (relative to 1 + the unit's largest entry), units above 5e-7
+must have an active joint-limit or contact row, smooth units <= 1e-7.
+
+Parity unpinned (stated where it applies): MuJoCo itself is unavailable offline, so "parity" is kernel vs oracle, both
+written from the same reading of MuJoCo's documented pipeline and pinned by the fixtures of DESIGN.md section 2.  One
+rule in particular was adopted by kernel and oracle together and has no fixture anywhere: crossing capsule axes
+(Hopper folded through itself) get the out-of-plane sphere/sphere normal and hence no row (planar_lean.hpp, sweep)."""
 import numpy as np
 import pytest
 
