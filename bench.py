@@ -295,7 +295,7 @@ def main():
                                          "correction); above the %d algorithmic bytes because inputs are gathered per lane -- "
                                          "harmless here, the kernel is VALU-bound" % (traffic_file, bytes_unit * N)
                                          if traffic else None,
-                         "kernel": "rollout_kernel<MdlHalfCheetah, false>" +
+                         "kernel": "rollout_kernel<MdlHalfCheetah, false, false>" +
                                    ("" if a.single_launch else " launched by mbrl_fd_jacobians_planned"),
                          "kernel_ms": kern_ms, "plan_ms": plan_ms,
                          "flops_per_launch_algorithmic": flops_alg, "flops_per_launch_executed_pmc": flops_exec,

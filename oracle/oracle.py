@@ -43,8 +43,25 @@ def lib():
                                        C.c_int, dp, dp, dp, dp, dp, dp, up, C.c_int]
         L.mjo_fd_jacobians_info.argtypes = L.mjo_fd_jacobians.argtypes[:-1] + [ip, C.c_int]
         L.mjo_stats.argtypes = [dp, dp, dp]
+        # mbrl_cpu.h: the oracle behind the call shapes of include/mbrl.h
+        vp, i64 = C.c_void_p, C.c_int64
+        L.mbrl_last_error_cpu.restype = C.c_char_p
+        L.mbrl_model_create_cpu.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
+        L.mbrl_model_destroy_cpu.argtypes = [vp]
+        L.mbrl_model_destroy_cpu.restype = None
+        L.mbrl_model_dims_cpu.argtypes = [vp, ip, ip, ip, dp]
+        L.mbrl_step_cpu.argtypes = [vp, i64] + [vp] * 8
+        L.mbrl_fd_jacobians_cpu.argtypes = [vp, i64, vp, vp, vp, C.c_double, C.c_int, C.c_int] + [vp] * 8
+        L.mbrl_vjp_scan_cpu.argtypes = [vp, i64, C.c_int, C.c_int] + [vp] * 8
+        L.mbrl_vjp_scan_layout_cpu.argtypes = [vp, i64, C.c_int, C.c_int, C.c_int] + [vp] * 8
+        L.mbrl_vjp_scan_sharded_cpu.argtypes = [vp, i64, C.c_int, C.c_int, C.c_int, i64, i64] + [vp] * 8
         _lib = L
     return _lib
+
+
+CPU_TWIN_SYMBOLS = ["mbrl_abi_version_cpu", "mbrl_model_create_cpu", "mbrl_model_destroy_cpu", "mbrl_model_dims_cpu",
+                    "mbrl_step_cpu", "mbrl_fd_jacobians_cpu", "mbrl_vjp_scan_cpu", "mbrl_vjp_scan_layout_cpu",
+                    "mbrl_vjp_scan_sharded_cpu", "mbrl_last_error_cpu"]
 
 
 def _p(a):

@@ -10,7 +10,7 @@ for line in open(root + "/summary.txt"):
     if m:
         v[m.group(1)] = float(m.group(2))
 fma, add, mul, tr = (v["SQ_INSTS_VALU_%s_F64" % k] for k in ("FMA", "ADD", "MUL", "TRANS"))
-rec = {"units": units, "fd_mode": fd_mode, "kernel": "rollout_kernel<MdlHalfCheetah,false> (mbrl_fd_jacobians_planned)",
+rec = {"units": units, "fd_mode": fd_mode, "kernel": "rollout_kernel<MdlHalfCheetah,false,false> (mbrl_fd_jacobians_planned)",
        "waves": v.get("SQ_WAVES"), "SQ_INSTS_VALU": v.get("SQ_INSTS_VALU"),
        "fma_f64": fma, "add_f64": add, "mul_f64": mul, "trans_f64": tr,
        "lane_flops_per_launch": 64.0 * (2 * fma + add + mul + tr),
