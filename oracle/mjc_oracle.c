@@ -94,7 +94,7 @@ typedef struct {
     int niter;
     unsigned status;
     /* stats */
-    long n_eval, n_eval_con, sum_iter, sum_nefc;
+    long n_eval, n_eval_con, sum_iter, sum_nefc, n_cross;   /* n_cross: contacts made by the crossing-axes rule */
 } Data;
 
 static Model g_models[MJO_NUM_RAW_MODELS];
@@ -391,6 +391,7 @@ static void sphereSphere(Data *d, const Contact *proto, const double *c1, double
     if (dist >= proto->includemargin) return;
     Contact c = *proto;
     if (len < 1e-10) {
+        d->n_cross++;
         double cr[3];
         cross3(cr, ax1, ax2);
         double n2 = dot3(cr, cr), l2 = dot3(ax1, ax1) * dot3(ax2, ax2);
@@ -1193,9 +1194,9 @@ static double rollout(const Model *m, Data *d, const double *qpos, const double 
     int nv = m->nv;
     double a[MJO_MAXU], r = 0;
     unsigned st = d->status;
-    long ne = d->n_eval, nc = d->n_eval_con, si = d->sum_iter, sn = d->sum_nefc;
+    long ne = d->n_eval, nc = d->n_eval_con, si = d->sum_iter, sn = d->sum_nefc, nx = d->n_cross;
     memset(d, 0, sizeof *d);
-    d->status = st; d->n_eval = ne; d->n_eval_con = nc; d->sum_iter = si; d->sum_nefc = sn;
+    d->status = st; d->n_eval = ne; d->n_eval_con = nc; d->sum_iter = si; d->sum_nefc = sn; d->n_cross = nx;
     load_state(m, d, qpos, qvel, ctrl);
     memcpy(a, ctrl, m->nu * sizeof(double));
     if (pert_kind == 1) a[idx] += delta;
@@ -1210,7 +1211,8 @@ static double rollout(const Model *m, Data *d, const double *qpos, const double 
 
 static int fd_impl(int id, int frame_skip, int64_t N, const double *qpos, const double *qvel, const double *ctrl,
                    double eps, int fd_mode, int nsteps, double *dsds, double *dsda, double *drds, double *drda,
-                   double *s_next, double *reward, uint32_t *status, int32_t *evals_constrained, int nthreads) {
+                   double *s_next, double *reward, uint32_t *status, int32_t *evals_constrained, int32_t *evals_crossing,
+                   int nthreads) {
     Model *m = get_model(id);
     if (!m) return -1;
     if (frame_skip <= 0) frame_skip = m->frame_skip;
@@ -1244,6 +1246,7 @@ static int fd_impl(int id, int frame_skip, int64_t N, const double *qpos, const 
         }
         if (status) status[i] = d.status;
         if (evals_constrained) evals_constrained[i] = (int32_t)d.n_eval_con;
+        if (evals_crossing) evals_crossing[i] = (int32_t)d.n_cross;
         if (nthreads <= 1) { g_n_eval += d.n_eval; g_n_eval_con += d.n_eval_con; g_sum_iter += d.sum_iter; g_sum_nefc += d.sum_nefc; }
     }
     return 0;
@@ -1253,17 +1256,19 @@ int mjo_fd_jacobians(int id, int frame_skip, int64_t N, const double *qpos, cons
                      double eps, int fd_mode, int nsteps, double *dsds, double *dsda, double *drds, double *drda,
                      double *s_next, double *reward, uint32_t *status, int nthreads) {
     return fd_impl(id, frame_skip, N, qpos, qvel, ctrl, eps, fd_mode, nsteps, dsds, dsda, drds, drda, s_next, reward, status,
-                   NULL, nthreads);
+                   NULL, NULL, nthreads);
 }
 
 /* The same, also reporting per unit how many dynamics evaluations of its rollouts (nominal and perturbed) had at least
  * one active constraint row -- joint limit or contact.  The full-size parity tests use it to tell the contact-rich units,
- * for which the FD tolerance is stated separately, from the smooth ones. */
+ * for which the FD tolerance is stated separately, from the smooth ones.  evals_crossing [N] (may be NULL): how many
+ * capsule/capsule contacts of the unit's rollouts were made by the crossing-axes rule of sphereSphere ("parity unpinned"). */
 int mjo_fd_jacobians_info(int id, int frame_skip, int64_t N, const double *qpos, const double *qvel, const double *ctrl,
                           double eps, int fd_mode, int nsteps, double *dsds, double *dsda, double *drds, double *drda,
-                          double *s_next, double *reward, uint32_t *status, int32_t *evals_constrained, int nthreads) {
+                          double *s_next, double *reward, uint32_t *status, int32_t *evals_constrained,
+                          int32_t *evals_crossing, int nthreads) {
     return fd_impl(id, frame_skip, N, qpos, qvel, ctrl, eps, fd_mode, nsteps, dsds, dsda, drds, drda, s_next, reward, status,
-                   evals_constrained, nthreads);
+                   evals_constrained, evals_crossing, nthreads);
 }
 
 int mjo_stats(double *mean_newton_iters, double *frac_evals_constrained, double *mean_nefc) {

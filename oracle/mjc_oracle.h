@@ -101,10 +101,12 @@ int mjo_fd_jacobians(int id, int frame_skip, int64_t N, const double *qpos, cons
 /* instrumentation: mean Newton iterations / active constraint statistics of the last call
  * (single-threaded calls only) */
 /* mjo_fd_jacobians that also reports, per unit, how many dynamics evaluations of its rollouts had an active constraint
- * row (joint limit or contact); evals_constrained [N]. */
+ * row (joint limit or contact); evals_constrained [N]; and how many capsule/capsule contacts were made by the
+ * crossing-axes rule ("parity unpinned"); evals_crossing [N], may be NULL. */
 int mjo_fd_jacobians_info(int id, int frame_skip, int64_t N, const double *qpos, const double *qvel, const double *ctrl,
                           double eps, int fd_mode, int nsteps, double *dsds, double *dsda, double *drds, double *drda,
-                          double *s_next, double *reward, uint32_t *status, int32_t *evals_constrained, int nthreads);
+                          double *s_next, double *reward, uint32_t *status, int32_t *evals_constrained,
+                          int32_t *evals_crossing, int nthreads);
 int mjo_stats(double *mean_newton_iters, double *frac_evals_constrained, double *mean_nefc);
 
 #ifdef __cplusplus

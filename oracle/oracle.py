@@ -41,7 +41,7 @@ def lib():
         L.mjo_step.argtypes = [C.c_int, C.c_int, C.c_int64, dp, dp, dp, dp, dp, dp, up, C.c_int]
         L.mjo_fd_jacobians.argtypes = [C.c_int, C.c_int, C.c_int64, dp, dp, dp, C.c_double, C.c_int,
                                        C.c_int, dp, dp, dp, dp, dp, dp, up, C.c_int]
-        L.mjo_fd_jacobians_info.argtypes = L.mjo_fd_jacobians.argtypes[:-1] + [ip, C.c_int]
+        L.mjo_fd_jacobians_info.argtypes = L.mjo_fd_jacobians.argtypes[:-1] + [ip, ip, C.c_int]
         L.mjo_stats.argtypes = [dp, dp, dp]
         # mbrl_cpu.h: the oracle behind the call shapes of include/mbrl.h
         vp, i64 = C.c_void_p, C.c_int64
@@ -138,7 +138,8 @@ class Oracle:
 
     def fd_jacobians(self, qpos, qvel, ctrl, eps=1e-6, fd_mode=0, nsteps=1, frame_skip=0, nthreads=1, info=False):
         """info=True: also out["evals_constrained"] [N], the number of dynamics evaluations of each unit's rollouts that
-        had an active joint-limit or contact row (0: the unit is smooth)."""
+        had an active joint-limit or contact row (0: the unit is smooth), and out["evals_crossing"] [N], the number of
+        capsule/capsule contacts made by the crossing-axes rule ("parity unpinned")."""
         qpos, qvel, ctrl = _c(qpos, (-1, self.nq)), _c(qvel, (-1, self.nv)), _c(ctrl, (-1, self.nu))
         N, n, nu = qpos.shape[0], self.n, self.nu
         out = dict(dsds=np.empty((N, n, n)), dsda=np.empty((N, n, nu)), drds=np.empty((N, n)),
@@ -149,7 +150,9 @@ class Oracle:
                 _p(out["s_next"]), _p(out["reward"]), out["status"].ctypes.data_as(up))
         if info:
             out["evals_constrained"] = np.zeros(N, dtype=np.int32)
-            rc = self.L.mjo_fd_jacobians_info(*args, out["evals_constrained"].ctypes.data_as(ip), nthreads)
+            out["evals_crossing"] = np.zeros(N, dtype=np.int32)
+            rc = self.L.mjo_fd_jacobians_info(*args, out["evals_constrained"].ctypes.data_as(ip),
+                                              out["evals_crossing"].ctypes.data_as(ip), nthreads)
         else:
             rc = self.L.mjo_fd_jacobians(*args, nthreads)
         if rc:

@@ -148,3 +148,19 @@ def test_body_masses_match_published_mujoco_values(env):
     got_kernel = np.array(compile_planar.PlanarModel(env).mass, dtype=float)     # the tables the HIP kernel is built from
     assert np.abs(got_oracle - want).max() < 5e-9
     assert np.abs(got_kernel - want).max() < 5e-9
+
+
+def test_oracle_counts_units_that_take_the_crossing_axes_rule():
+    """The crossing-capsule-axes rule is "parity unpinned": the oracle reports which units' rollouts met
+    it, so that parity figures can state how many of their units rest on it.  Only Hopper's MJCF has capsule pairs."""
+    import util
+    from oracle import Oracle
+    o = Oracle("HopperEnv")
+    q, v, c = util.on_trajectory(o, "HopperEnv", 256, seed=0, max_steps=39)
+    out = o.fd_jacobians(q, v, c, nthreads=8, info=True)
+    x = out["evals_crossing"]
+    assert (x >= 0).all() and (x > 0).any()                     # Hopper falls and folds through itself within the horizon
+    print("Hopper: %d of %d on-trajectory units took the crossing-axes rule" % (int((x > 0).sum()), len(x)))
+    h = Oracle("HalfCheetahEnv")
+    q, v, c = util.on_trajectory(h, "HalfCheetahEnv", 64, seed=0, max_steps=20)
+    assert not h.fd_jacobians(q, v, c, nthreads=8, info=True)["evals_crossing"].any()
