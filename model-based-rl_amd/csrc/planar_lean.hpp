@@ -33,6 +33,7 @@
 #include <cstdint>
 
 #include "models_gen.hpp"
+#include "wave_or.hpp"
 
 #if defined(__HIPCC__)
 #define MBRL_HD __host__ __device__ __forceinline__
@@ -57,6 +58,7 @@
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MBRL_LOOP_FENCE asm volatile("" ::: "memory")
 #define MBRL_OPAQUE(x) asm volatile("" : "+v"(x))
+#define MBRL_OPAQUE_S(x) asm volatile("" : "+s"(x))     // the same for a wave-uniform value (stays in a scalar register)
 #define MBRL_WAVE_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0)   // true in every active lane if any active lane has c
 // Placed right after a row prefetch (Pop::next, which ends in a fence the loads cannot cross): everything computed from x
 // is ordered AFTER the loads, so they are issued at the top of the block and their latency runs under the block's own
@@ -70,6 +72,7 @@
 #else
 #define MBRL_LOOP_FENCE
 #define MBRL_OPAQUE(x)
+#define MBRL_OPAQUE_S(x)
 #define MBRL_WAVE_ANY(c) (c)
 #define MBRL_ANCHOR(x)
 #endif
@@ -354,6 +357,29 @@ struct Lean {
     // constraints in DESCENDING order, so they pop the stacks top-down and always have the rows of the
     // next active constraint in flight while they work on the current one (LDS latency is otherwise
     // fully exposed at one wave per SIMD).
+    // Rows that are active in ANY lane of this wave (wave-uniform; -DMBRL_NO_WAVE_ROWS turns it off): cand_on | lim_on << NCAND |
+    // pair_on << (NCAND + NV), OR-ed over the wave once per dynamics evaluation.  The solver passes test it with scalar
+    // branches before they test their own lane's bit: a row nobody has then costs a scalar compare and branch instead of
+    // a vector compare feeding s_and_saveexec (11 against ~50 clocks for a lone wave, tools/micro/branch_cost2.hip).
+    uint32_t wave_rows;
+#if defined(MBRL_NO_WAVE_ROWS)
+    static constexpr bool kWaveRows = false;    // A/B: every row test is the lane's own (round 3 before this change)
+#else
+    static constexpr bool kWaveRows = true;
+#endif
+    static_assert(Layout<M, KCAP>::NCAND + M::NV + M::NPAIR <= 32, "the wave-wide row mask is one 32-bit word");
+    // (each test reads its own opaque copy: left to itself the compiler evaluates all of them ahead of the solver loops
+    // and keeps thirty 64-bit booleans alive in scalar registers, which then spill into VGPR lanes)
+    static constexpr uint32_t low_bits(int n) { return n >= 32 ? ~0u : (n <= 0 ? 0u : (1u << n) - 1u); }
+    MBRL_HD bool w_test(uint32_t bits) const {
+        if (!kWaveRows) return true;
+        uint32_t w = wave_rows;
+        MBRL_OPAQUE_S(w);
+        return (w & bits) != 0;
+    }
+    MBRL_HD bool w_cand(uint32_t bits) const { return w_test(bits); }
+    MBRL_HD bool w_lim(uint32_t bits) const { return w_test(bits << Layout<M, KCAP>::NCAND); }
+    MBRL_HD bool w_pair(uint32_t bits) const { return w_test(bits << (Layout<M, KCAP>::NCAND + M::NV)); }
     uint32_t lim_on, lim_hi;             // bit j: limit row of dof j active / it is the upper limit
     uint32_t cand_on;                    // bit c: floor candidate (capsule end) c is in contact and owns a slot
     int nslot, nlimrow;                  // heights of the two stacks
@@ -1026,10 +1052,11 @@ struct Lean {
         Pop<LY::OL, 2> ls;
         if (M::HAS_FLOOR) cs.start(mem, nslot);
         if (LY::NLIM > 0) ls.start(mem, nlimrow);
-        if (MBRL_RARE(lim_on != 0)) {     // one test for all limit rows: active joint limits are rare
+        if (kWaveRows ? w_lim(low_bits(NV)) : MBRL_RARE(lim_on != 0)) {     // one test for all limit rows: active joint limits are rare
             MBRL_UNROLL
             for (int j = NV - 1; j >= 0; j--) {
                 if (!M::limited[j]) continue;
+                if (!w_lim(1u << j)) continue;
                 if (lim_on & (1u << j)) {
                     const T D = ls.cur[0], aref = ls.cur[1];
                     ls.next(mem);
@@ -1042,6 +1069,7 @@ struct Lean {
         }
         MBRL_UNROLL
         for (int k = 0; k < M::NPAIR; k++) {
+            if (!w_pair(1u << k)) continue;
             if (pair_on & (1u << k)) {
                 const int b1 = M::g_body[M::pair_g1[k]], b2 = M::g_body[M::pair_g2[k]];
                 const int o = LY::OP + 5 * k;
@@ -1053,15 +1081,18 @@ struct Lean {
                 if (t_val(r) < 0.0) { lm |= 1u << (NV + k); g = g + D * r * jv; h = h + D * jv * jv; }
             }
         }
-        if (!M::HAS_FLOOR || cand_on == 0) return;
+        if (!M::HAS_FLOOR) return;
+        if (kWaveRows ? !w_cand(low_bits(LY::NCAND)) : cand_on == 0) return;
         int csh = 3 * (nslot - 1);
         MBRL_UNROLL
         for (int gi = M::NGEOM - 1; gi >= 0; gi--) {
             if (!M::c_on[gi]) continue;
-            if (!MBRL_RARE(cand_on & (3u << TP::T.cand_rank[gi][0]))) continue;   // neither end of this capsule
+            if (kWaveRows ? !w_cand(3u << TP::T.cand_rank[gi][0])
+                          : !MBRL_RARE(cand_on & (3u << TP::T.cand_rank[gi][0]))) continue;   // neither end of this capsule
             const int b = M::g_body[gi];
             MBRL_UNROLL
             for (int e = 1; e >= 0; e--) {
+                if (!w_cand(1u << TP::T.cand_rank[gi][e])) continue;
                 if (cand_on & (1u << TP::T.cand_rank[gi][e])) {
                     const T Pa = cs.cur[0], Pb = cs.cur[1], D = cs.cur[2], arn = cs.cur[3], art = cs.cur[4];
                     const int sh = csh;
@@ -1165,6 +1196,7 @@ struct Lean {
         // ---- capsule/capsule pairs (b1 is an ancestor of b2: the row acts on the dofs between them) ----
         MBRL_UNROLL
         for (int k = 0; k < M::NPAIR; k++) {
+            if (!w_pair(1u << k)) continue;
             if (pair_on & (1u << k)) {
                 const int o = LY::OP + 5 * k;
                 const T w0 = mem.ld(o), w1 = mem.ld(o + 1), w2 = mem.ld(o + 2), D = mem.ld(o + 3), aref = mem.ld(o + 4);
@@ -1196,17 +1228,19 @@ struct Lean {
         }
         // ---- floor contacts ----
         if (M::HAS_FLOOR) {
-            if (MBRL_RARE(cand_on != 0)) {
+            if (kWaveRows ? w_cand(low_bits(LY::NCAND)) : MBRL_RARE(cand_on != 0)) {
                 Pop<LY::OS, 5> cs;
                 cs.start(mem, nslot);
                 int csh = 3 * (nslot - 1);          // bit position of the top slot's rows in `cm`
                 MBRL_UNROLL
                 for (int g = M::NGEOM - 1; g >= 0; g--) {
                     if (!M::c_on[g]) continue;
-                    if (!MBRL_RARE(cand_on & (3u << TP::T.cand_rank[g][0]))) continue;   // neither end of this capsule
+                    if (kWaveRows ? !w_cand(3u << TP::T.cand_rank[g][0])
+                                  : !MBRL_RARE(cand_on & (3u << TP::T.cand_rank[g][0]))) continue;   // neither end of this capsule
                     const int b = M::g_body[g];
                     MBRL_UNROLL
                     for (int e = 1; e >= 0; e--) {
+                        if (!w_cand(1u << TP::T.cand_rank[g][e])) continue;
                         if (cand_on & (1u << TP::T.cand_rank[g][e])) {
                             T Pa = cs.cur[0], Pb = cs.cur[1];
                             const T D = cs.cur[2], arn = cs.cur[3], art = cs.cur[4];
@@ -1270,12 +1304,13 @@ struct Lean {
         }
         // ---- joint limits ----
         if (LY::NLIM > 0) {
-            if (MBRL_RARE(lim_on != 0)) {
+            if (kWaveRows ? w_lim(low_bits(NV)) : MBRL_RARE(lim_on != 0)) {
                 Pop<LY::OL, 2> ls;
                 ls.start(mem, nlimrow);
                 MBRL_UNROLL
                 for (int i = NV - 1; i >= 0; i--) {
                     if (!M::limited[i]) continue;
+                    if (!w_lim(1u << i)) continue;
                     if (lim_on & (1u << i)) {
                         T D = ls.cur[0], aref = ls.cur[1];
                         ls.next(mem);
@@ -1467,6 +1502,11 @@ struct Lean {
         MBRL_PHASE(0);
         const bool constrained = (lim_on | cand_on | pair_on) != 0;
         was_constrained = constrained;
+        // the wave-wide OR of the row masks goes through the LDS while HM is built and factorised
+        const uint32_t my_rows = cand_on | (lim_on << LY::NCAND) | (pair_on << (LY::NCAND + NV));
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (kWaveRows) wave_or_begin(my_rows);
+#endif
         // Start of the solver: the unconstrained acceleration.  (Starting from the previous mj_step's solution was
         // measured: it does not lower the number of Newton passes on on-trajectory HalfCheetah states, 2.67 vs 2.57
         // per constrained step.)
@@ -1496,6 +1536,11 @@ struct Lean {
             solve(H, qacc);
         }
         MBRL_PIN(qacc, NV);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (kWaveRows) wave_rows = wave_or_end();
+#else
+        wave_rows = my_rows;
+#endif
         MBRL_MARK("unconstrained_end");
         MBRL_PHASE(1);
         MBRL_UNROLL
