@@ -365,7 +365,9 @@ struct Lean {
 #if defined(MBRL_NO_WAVE_ROWS)
     static constexpr bool kWaveRows = false;    // A/B: every row test is the lane's own (round 3 before this change)
 #else
-    static constexpr bool kWaveRows = true;
+    // Models with floor contacts only: with the one or two limit rows of the pendulums and the swimmer there is nothing
+    // to skip, and the LDS round trip costs them 2-3 % (profiles/r03_sweep.md before / after).
+    static constexpr bool kWaveRows = M::HAS_FLOOR;
 #endif
     static_assert(Layout<M, KCAP>::NCAND + M::NV + M::NPAIR <= 32, "the wave-wide row mask is one 32-bit word");
     // (each test reads its own opaque copy: left to itself the compiler evaluates all of them ahead of the solver loops
