@@ -123,7 +123,7 @@ struct WaveMap {
 #else
 #define MBRL_PLAN_SLOT(slot) (N - 1 - (slot))
 #endif
-constexpr int kKeyBits = 62;   // Lean::key_value: solver passes per mj_step + line-search tie-break, or total / row union / passes
+constexpr int kKeyBits = 62;   // Lean::key_value: floor-contact union, solver passes (per mj_step; long rollouts: total first), limit / pair union
 constexpr int PLAN_NONE = 0, PLAN_WRITE = 1, PLAN_READ = 2, PLAN_RECORD = 3;   // RECORD: keys only (mbrl_step_record)
 constexpr unsigned ST_BADPLAN = MBRL_ST_BADPLAN;
 struct PlanHeader {

@@ -390,12 +390,15 @@ struct Lean {
     unsigned status;
     int newton_iters;
     // Control-flow signature of the rollout (the launch planner sorts the units by it, mbrl_fd_plan; units with equal
-    // signatures take the same branches).  Rollouts of up to 10 mj_steps: 3 bits of Hessian passes per step, oldest step
-    // most significant, then 3 bits per step of line-search evaluations as the tie-break (key2).  Longer rollouts
-    // (Hopper 20, Walker2d 25 steps): [passes of the whole rollout / 4 : 6 bits][rows that were EVER active (floor
-    // candidates, limits, pairs) : KEY_U bits][2 bits per step of passes, first KEY_REC steps] -- measured against a dozen
-    // other orders with tools/key_probe.py, profiles/r02_experiments.md.  key2 then carries the row union in bits 0..23
-    // and the pass total in bits 24..31.
+    // signatures take the same branches).  Accumulated per mj_step by key_note, assembled by key_value:
+    //   rollouts of up to 10 mj_steps:  [floor contacts that were EVER active][3 bits of Hessian passes per step, oldest
+    //     step most significant][limits / pairs that were ever active];
+    //   longer ones (Hopper 20, Walker2d 25 steps):  [floor contacts ever active][passes of the whole rollout / 4 : 6 bits]
+    //     [2 bits of passes per step, first KEY_REC steps][limits / pairs ever active].
+    // While it accumulates, `key` holds the per-step pass counts and key2 the row union (bits 0..23; long rollouts keep
+    // the pass total in bits 24..31).  Round 2 chose pass counts first from a dozen orders (tools/key_probe.py,
+    // profiles/r02_experiments.md; -DMBRL_KEY_ROUND2 restores it); with the wave-wide row mask, units that share their
+    // contacts are worth more together: ten layouts re-measured in profiles/r03_experiments.md.
     uint64_t key;
     uint32_t key2;
     int key_left;                        // long rollouts: steps still to record; -1: short rollout
@@ -1612,7 +1615,11 @@ struct Lean {
         const uint32_t p7 = passes < 7u ? passes : 7u;
         if (key_left < 0) {
             key = (key << 3) | uint64_t(p7);
+#if defined(MBRL_KEY_ROUND2)
             key2 = (key2 << 3) | (line_evals < 7u ? line_evals : 7u);
+#else
+            key2 |= rows;                                   // the union of the rows that were ever active
+#endif
             return;
         }
         if (key_left > 0) {
@@ -1624,9 +1631,27 @@ struct Lean {
         key2 = ((key2 | rows) & 0xffffffu) | (tot << 24);
     }
     MBRL_HD uint64_t key_value(int steps) const {
+        // Layouts since the wave-wide row mask (profiles/r03_experiments.md, ten layouts measured): units that share
+        // their floor contacts share a wave -- the solver passes then skip the other contacts' rows with scalar branches --
+        // and inside such a group the pass counts order them as before.
+#if defined(MBRL_KEY_ROUND2)
         if (steps <= 10) return ((key & 0x3fffffffull) << 32) | uint64_t(key2 & 0x3fffffffu);
+#else
+        if (steps <= 10) {   // [floor-contact union][3 bits of passes per step][limit / pair union]
+            const uint32_t u = key2 & 0xffffffu, cu = u & low_bits(LY::NCAND), ru = u >> LY::NCAND;
+            return (uint64_t(cu) << 38) | ((key & 0x3fffffffull) << 8) | uint64_t(ru & 0xffu);
+        }
+#endif
         const uint32_t tq = (key2 >> 26) < 63u ? (key2 >> 26) : 63u;           // pass total / 4
+#if defined(MBRL_KEY_ROUND2)
         return (uint64_t(tq) << (KEY_U + 2 * KEY_REC)) | (uint64_t(key2 & ((1u << KEY_U) - 1u)) << (2 * KEY_REC)) | key;
+#else
+        {   // [floor-contact union][pass total / 4][2 bits of passes per recorded step][limit / pair union]
+            const uint32_t u = key2 & ((1u << KEY_U) - 1u), cu = u & low_bits(LY::NCAND), ru = u >> LY::NCAND;
+            constexpr int RB = KEY_U - LY::NCAND;
+            return (uint64_t(cu) << (6 + 2 * KEY_REC + RB)) | (uint64_t(tq) << (2 * KEY_REC + RB)) | (key << RB) | uint64_t(ru);
+        }
+#endif
     }
 
     MBRL_HD void step() {
