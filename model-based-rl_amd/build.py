@@ -8,7 +8,7 @@ from . import compile_planar
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libmbrl_hip.so")
-SOURCES = ["mbrl_hip.hip", "planar_lean.hpp", "models_gen.hpp"]
+SOURCES = ["mbrl_hip.hip", "planar_lean.hpp", "wave_or.hpp", "models_gen.hpp"]
 
 
 def _hipcc():
